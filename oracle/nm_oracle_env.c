@@ -1,0 +1,334 @@
+/* nm_oracle_env.c - CPU restatement of NightmareV3Env (reference envs/nightmare_v3_env.py).
+ *
+ * TEST INFRASTRUCTURE ONLY (see nm_oracle.h). Each block cites the reference lines it follows.
+ * Pinned by golden vectors generated from the reference class itself (tests/golden/make_goldens.py).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#include "nm_oracle.h"
+
+#include "../nightmare_rl_amd/model/nm_model_data.h"
+
+/* config constants: reference envs/nightmare_v3_config.py */
+#define DECIMATION 2            /* :45 */
+#define P_GAIN 20.0             /* :36 */
+#define ACTION_SCALE_F 0.2f     /* :46 (float32 product, see step()) */
+#define CLIP_ACTIONS_F 1.0f     /* :74 */
+#define CLIP_OBS 100.0          /* :73 */
+#define OBS_LIN_VEL 2.0         /* :68 */
+#define OBS_ANG_VEL 0.25        /* :69 */
+#define OBS_DOF_POS 1.0         /* :70 */
+#define OBS_DOF_VEL 0.05        /* :71 */
+#define MAX_LIN_VEL_X 0.5       /* :62 */
+#define MAX_ANG_VEL 0.8         /* :64 */
+#define TERM_CONTACT_FORCE 160.0 /* :22 */
+#define TRACKING_SIGMA 0.008    /* :98 */
+#define EPISODE_LENGTH_S 20.0   /* :14 */
+#define RESAMPLING_TIME 10.0    /* :60 */
+static const double kPi = 3.14159265358979323846;
+
+enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
+
+struct nmo_env {
+  int N, nthreads;
+  uint64_t seed;
+  int64_t env_off;
+  double dt, max_episode_length;
+  int resample_every;
+  double scale[NMO_NREW]; /* reward scale * dt (env.py:123-128) */
+  nmo_data* data;
+  nmo_scratch* scratch; /* per thread */
+  double *dof_pos, *dof_vel, *commands, *episode_sums;
+  float *actions, *prev_actions;
+  int64_t* ep_len;
+  uint32_t* rng_ctr;
+  /* last-step debug */
+  double *blv, *bav, *pg, *tibia, *feet, *body, *rew_terms;
+  int64_t* reset_buf;
+  uint8_t* time_out;
+  double ep_stats[NMO_NREW];
+  int last_nreset;
+};
+
+double nmo_rand_u24(uint64_t seed, uint64_t genv, uint32_t ctr) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (genv + 1) + 0xD1B54A32D192ED03ull * (uint64_t)ctr;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (double)(x >> 40) * (1.0 / 16777216.0);
+}
+
+nmo_env* nmo_env_create(int N, uint64_t seed, int64_t env_off, int nthreads) {
+  nmo_env* e = (nmo_env*)calloc(1, sizeof *e);
+  e->N = N; e->seed = seed; e->env_off = env_off; e->nthreads = nthreads < 1 ? 1 : nthreads;
+  e->dt = NM_TIMESTEP * DECIMATION;                               /* env.py:99 */
+  e->max_episode_length = ceil(EPISODE_LENGTH_S / e->dt);         /* env.py:101 */
+  e->resample_every = (int)(RESAMPLING_TIME / e->dt);             /* env.py:235 */
+  /* reward scales (config.py:78-86) times dt, alphabetical order (helpers.py:7 iterates dir()) */
+  e->scale[R_ACTION_RATE] = -0.02 * e->dt;
+  e->scale[R_BODY_CONTACT] = -5.0 * e->dt;
+  e->scale[R_DEFAULT_POS] = -0.01 * e->dt;
+  e->scale[R_DOF_ACC] = -2.5e-5 * e->dt;
+  e->scale[R_ORIENTATION] = -5.0 * e->dt;
+  e->scale[R_TRACK_ANG] = 6.0 * e->dt;
+  e->scale[R_TRACK_LIN] = 8.0 * e->dt;
+  e->scale[R_TERMINATION] = -200.0 * e->dt;
+  e->data = (nmo_data*)calloc(N, sizeof(nmo_data));
+  e->scratch = (nmo_scratch*)calloc(e->nthreads, sizeof(nmo_scratch));
+  for (int i = 0; i < N; i++) nmo_reset_data(&e->data[i]);
+#define AL(p, T, n) e->p = (T*)calloc((size_t)(n), sizeof(T))
+  AL(dof_pos, double, N * 18); AL(dof_vel, double, N * 18); AL(commands, double, N * 3);
+  AL(episode_sums, double, NMO_NREW * N); AL(actions, float, N * 18); AL(prev_actions, float, N * 18);
+  AL(ep_len, int64_t, N); AL(rng_ctr, uint32_t, N);
+  AL(blv, double, N * 3); AL(bav, double, N * 3); AL(pg, double, N * 3); AL(tibia, double, N * 6);
+  AL(feet, double, N * 6); AL(body, double, N); AL(rew_terms, double, NMO_NREW * N);
+  AL(reset_buf, int64_t, N); AL(time_out, uint8_t, N);
+#undef AL
+  return e;
+}
+void nmo_env_destroy(nmo_env* e) {
+  if (!e) return;
+  free(e->data); free(e->scratch); free(e->dof_pos); free(e->dof_vel); free(e->commands); free(e->episode_sums);
+  free(e->actions); free(e->prev_actions); free(e->ep_len); free(e->rng_ctr); free(e->blv); free(e->bav); free(e->pg);
+  free(e->tibia); free(e->feet); free(e->body); free(e->rew_terms); free(e->reset_buf); free(e->time_out);
+  free(e);
+}
+nmo_data* nmo_env_data(nmo_env* e, int i) { return &e->data[i]; }
+
+/* _resample_commands for one env (env.py:321-333); ux/uyaw uniforms in [0,1) */
+static void resample(nmo_env* e, int i, const double* u) {
+  double ux, uy;
+  if (u) { ux = u[0]; uy = u[1]; }
+  else {
+    ux = nmo_rand_u24(e->seed, (uint64_t)(e->env_off + i), e->rng_ctr[i]);
+    uy = nmo_rand_u24(e->seed, (uint64_t)(e->env_off + i), e->rng_ctr[i] + 1);
+    e->rng_ctr[i] += 2;
+  }
+  double* c = e->commands + 3 * i;
+  c[0] = ux * 2 * MAX_LIN_VEL_X - MAX_LIN_VEL_X;
+  c[1] = 0;
+  c[2] = uy * 2 * MAX_ANG_VEL - MAX_ANG_VEL;
+  double keep = sqrt(c[0] * c[0] + c[1] * c[1]) > 0.02 ? 1.0 : 0.0; /* :333 */
+  c[0] *= keep; c[1] *= keep;
+}
+
+/* the per-env part of reset_idx (env.py:348-361); stats are gathered by the caller */
+static void reset_one(nmo_env* e, int i, const double* u) {
+  nmo_data* d = &e->data[i];
+  for (int k = 0; k < NMO_NQ; k++) d->qpos[k] = nm_qpos0[k]; /* :349 model.qpos0 (mjmodel.xml:33) */
+  for (int k = 0; k < NMO_NV; k++) d->qvel[k] = 0;                                       /* :350 */
+  resample(e, i, u);                                                                     /* :356 */
+  e->ep_len[i] = 0;                                                                      /* :360 */
+  e->reset_buf[i] = 1;                                                                   /* :361 */
+}
+static void episode_stats(nmo_env* e, const int32_t* ids, int n) { /* env.py:363-367 */
+  for (int k = 0; k < NMO_NREW; k++) {
+    double s = 0;
+    for (int j = 0; j < n; j++) { int i = ids ? ids[j] : j; s += e->episode_sums[k * e->N + i]; }
+    e->ep_stats[k] = (float)(s / n / EPISODE_LENGTH_S); /* torch.tensor(..., dtype=float32) */
+    for (int j = 0; j < n; j++) { int i = ids ? ids[j] : j; e->episode_sums[k * e->N + i] = 0; }
+  }
+}
+void nmo_env_reset_idx(nmo_env* e, const int32_t* ids, int n, const double* cmd_u) {
+  if (!ids) n = e->N;
+  if (n == 0) return; /* :344 */
+  for (int j = 0; j < n; j++) reset_one(e, ids ? ids[j] : j, cmd_u ? cmd_u + 2 * j : NULL);
+  episode_stats(e, ids, n);
+  e->last_nreset = n;
+}
+
+static void neg_quat(double* r, const double* q) { r[0] = q[0]; r[1] = -q[1]; r[2] = -q[2]; r[3] = -q[3]; }
+static void rot_vec_quat(double* r, const double* v, const double* q) { /* mju_rotVecQuat */
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  double tx = 2 * (y * v[2] - z * v[1]), ty = 2 * (z * v[0] - x * v[2]), tz = 2 * (x * v[1] - y * v[0]);
+  r[0] = v[0] + w * tx + (y * tz - z * ty);
+  r[1] = v[1] + w * ty + (z * tx - x * tz);
+  r[2] = v[2] + w * tz + (x * ty - y * tx);
+}
+/* numpy float32 pairwise sum of n<128 contiguous values (8 accumulators, then the tail) */
+static float np_sum_f32(const float* a, int n) {
+  if (n < 8) { float r = 0; for (int i = 0; i < n; i++) r += a[i]; return r; }
+  float r[8];
+  for (int k = 0; k < 8; k++) r[k] = a[k];
+  int i;
+  for (i = 8; i < n - (n % 8); i += 8)
+    for (int k = 0; k < 8; k++) r[k] += a[i + k];
+  float res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; i++) res += a[i];
+  return res;
+}
+
+void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done,
+                  float* time_outs, double* obs64, double* rew64) {
+  const int N = e->N;
+  const double default_pos[3] = {0.0, kPi / 5, 0.0}; /* config.py:39-44 */
+  /* E1 (env.py:152-156,181-192): float32 scale+clip, PD -> velocity ctrl using the env's own (possibly stale) dof_pos */
+  memcpy(e->prev_actions, e->actions, sizeof(float) * N * 18);
+  for (int i = 0; i < N * 18; i++) {
+    float a = actions[i] * ACTION_SCALE_F;
+    e->actions[i] = a < -CLIP_ACTIONS_F ? -CLIP_ACTIONS_F : (a > CLIP_ACTIONS_F ? CLIP_ACTIONS_F : a);
+  }
+  double* prev_dof_vel = (double*)malloc(sizeof(double) * N * 18);
+  memcpy(prev_dof_vel, e->dof_vel, sizeof(double) * N * 18);
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < 18; j++)
+      e->data[i].ctrl[j] = (((double)e->actions[i * 18 + j] - default_pos[j % 3]) - e->dof_pos[i * 18 + j]) * P_GAIN;
+    /* E2 (env.py:195-210): mj_step(model, data[i], decimation) fanned out over threads */
+#pragma omp parallel for num_threads(e->nthreads) schedule(static)
+  for (int i = 0; i < N; i++) {
+#ifdef _OPENMP
+    nmo_scratch* s = &e->scratch[omp_get_thread_num()];
+#else
+    nmo_scratch* s = &e->scratch[0];
+#endif
+    nmo_step(&e->data[i], s, DECIMATION);
+  }
+  /* E3 (env.py:212-232) */
+  const double grav[3] = {0, 0, -9.81}; /* env.py:46 */
+  for (int i = 0; i < N; i++) {
+    nmo_data* d = &e->data[i];
+    e->ep_len[i] += 1;
+    double bq[4];
+    neg_quat(bq, d->qpos + 3);
+    rot_vec_quat(e->blv + 3 * i, d->cvel[1] + 3, bq);
+    rot_vec_quat(e->bav + 3 * i, d->cvel[1], bq);
+    rot_vec_quat(e->pg + 3 * i, grav, bq);
+    for (int j = 0; j < 18; j++) { e->dof_pos[i * 18 + j] = d->qpos[7 + j]; e->dof_vel[i * 18 + j] = d->qvel[6 + j]; }
+    for (int j = 0; j < 6; j++) { e->tibia[i * 6 + j] = d->sensordata[j]; e->feet[i * 6 + j] = d->sensordata[6 + j]; }
+    e->body[i] = d->sensordata[12];
+    for (int j = 0; j < 6; j++) e->tibia[i * 6 + j] *= (e->feet[i * 6 + j] == 0) ? 1.0 : 0.0; /* :232 */
+  }
+  /* E4 (env.py:235-236) periodic command resample */
+  for (int i = 0; i < N; i++)
+    if (e->ep_len[i] % e->resample_every == 0) resample(e, i, cmd_u ? cmd_u + 4 * i : NULL);
+  /* E5 (env.py:239-258) termination */
+  const double max_angle = 60 * kPi / 180;
+  int nreset = 0;
+  int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * (N > 0 ? N : 1));
+  for (int i = 0; i < N; i++) {
+    int to = (double)e->ep_len[i] > e->max_episode_length;
+    int r = to;
+    double fmaxv = e->feet[i * 6];
+    for (int j = 1; j < 6; j++) fmaxv = e->feet[i * 6 + j] > fmaxv ? e->feet[i * 6 + j] : fmaxv;
+    r |= fmaxv > TERM_CONTACT_FORCE;
+    const double* pg = e->pg + 3 * i;
+    double nrm = sqrt(pg[0] * pg[0] + pg[1] * pg[1] + pg[2] * pg[2]);
+    r |= acos(-pg[2] / nrm) > max_angle;
+    e->time_out[i] = (uint8_t)to;
+    e->reset_buf[i] = r;
+    if (r) ids[nreset++] = i;
+  }
+  /* E6 (env.py:274): reset BEFORE rewards / observations */
+  e->last_nreset = nreset;
+  if (nreset) {
+    for (int j = 0; j < nreset; j++) reset_one(e, ids[j], cmd_u ? cmd_u + 4 * ids[j] + 2 : NULL);
+    episode_stats(e, ids, nreset);
+  }
+  free(ids);
+  /* E7 (env.py:277-288) rewards, alphabetical order, termination last */
+  for (int i = 0; i < N; i++) {
+    double t[NMO_NREW];
+    float sq[18];
+    for (int j = 0; j < 18; j++) { float df = e->prev_actions[i * 18 + j] - e->actions[i * 18 + j]; sq[j] = df * df; }
+    t[R_ACTION_RATE] = (double)(np_sum_f32(sq, 18) * (float)e->scale[R_ACTION_RATE]); /* float32 array * python float */
+    double sum = 0;
+    for (int j = 0; j < 6; j++) sum += e->tibia[i * 6 + j];
+    t[R_BODY_CONTACT] = (sum + e->body[i]) * e->scale[R_BODY_CONTACT];
+    sum = 0;
+    for (int j = 0; j < 18; j++) { double df = e->dof_pos[i * 18 + j] - default_pos[j % 3]; sum += df * df; }
+    t[R_DEFAULT_POS] = sum * e->scale[R_DEFAULT_POS];
+    sum = 0;
+    for (int j = 0; j < 18; j++) { double acc = (e->dof_vel[i * 18 + j] - prev_dof_vel[i * 18 + j]) / e->dt; sum += acc * acc; }
+    t[R_DOF_ACC] = sum * e->scale[R_DOF_ACC];
+    const double *pg = e->pg + 3 * i, *c = e->commands + 3 * i, *v = e->blv + 3 * i, *w = e->bav + 3 * i;
+    t[R_ORIENTATION] = (pg[0] * pg[0] + pg[1] * pg[1]) * e->scale[R_ORIENTATION];
+    double ea = (c[2] - w[2]) * (c[2] - w[2]);
+    t[R_TRACK_ANG] = exp(-ea / TRACKING_SIGMA) * e->scale[R_TRACK_ANG];
+    double el = (c[0] - v[0]) * (c[0] - v[0]) + (c[1] - v[1]) * (c[1] - v[1]);
+    t[R_TRACK_LIN] = exp(-el / TRACKING_SIGMA) * e->scale[R_TRACK_LIN];
+    t[R_TERMINATION] = (double)(e->reset_buf[i] * (e->time_out[i] ? 0 : 1)) * e->scale[R_TERMINATION];
+    double r = 0;
+    for (int k = 0; k < NMO_NREW; k++) {
+      r += t[k];
+      e->episode_sums[k * N + i] += t[k];
+      e->rew_terms[k * N + i] = t[k];
+    }
+    if (rew) rew[i] = (float)r;
+    if (rew64) rew64[i] = r;
+    /* E8 (env.py:291-311) observation */
+    double o[66];
+    for (int k = 0; k < 3; k++) {
+      o[k] = v[k] * OBS_LIN_VEL;
+      o[3 + k] = w[k] * OBS_ANG_VEL;
+      o[6 + k] = pg[k];
+    }
+    o[9] = c[0] * OBS_LIN_VEL; o[10] = c[1] * OBS_LIN_VEL; o[11] = c[2] * OBS_ANG_VEL;
+    for (int j = 0; j < 18; j++) {
+      o[12 + j] = (e->dof_pos[i * 18 + j] - default_pos[j % 3]) * OBS_DOF_POS;
+      o[30 + j] = e->dof_vel[i * 18 + j] * OBS_DOF_VEL;
+      o[48 + j] = (double)e->actions[i * 18 + j];
+    }
+    for (int k = 0; k < 66; k++) {
+      double x = o[k] < -CLIP_OBS ? -CLIP_OBS : (o[k] > CLIP_OBS ? CLIP_OBS : o[k]);
+      if (obs) obs[i * 66 + k] = (float)x;
+      if (obs64) obs64[i * 66 + k] = x;
+    }
+    if (done) done[i] = e->reset_buf[i];
+    if (time_outs) time_outs[i] = (float)e->time_out[i];
+  }
+  free(prev_dof_vel);
+}
+
+void nmo_env_get_state(nmo_env* e, double* qpos, double* qvel, double* qw) {
+  for (int i = 0; i < e->N; i++) {
+    if (qpos) memcpy(qpos + i * NMO_NQ, e->data[i].qpos, sizeof(double) * NMO_NQ);
+    if (qvel) memcpy(qvel + i * NMO_NV, e->data[i].qvel, sizeof(double) * NMO_NV);
+    if (qw) memcpy(qw + i * NMO_NV, e->data[i].qacc_warmstart, sizeof(double) * NMO_NV);
+  }
+}
+void nmo_env_set_state(nmo_env* e, const double* qpos, const double* qvel, const double* qw) {
+  for (int i = 0; i < e->N; i++) {
+    if (qpos) memcpy(e->data[i].qpos, qpos + i * NMO_NQ, sizeof(double) * NMO_NQ);
+    if (qvel) memcpy(e->data[i].qvel, qvel + i * NMO_NV, sizeof(double) * NMO_NV);
+    if (qw) memcpy(e->data[i].qacc_warmstart, qw + i * NMO_NV, sizeof(double) * NMO_NV);
+  }
+}
+void nmo_env_get_buffers(nmo_env* e, double* dof_pos, double* dof_vel, double* actions, double* commands, int64_t* ep_len,
+                         double* episode_sums) {
+  int N = e->N;
+  if (dof_pos) memcpy(dof_pos, e->dof_pos, sizeof(double) * N * 18);
+  if (dof_vel) memcpy(dof_vel, e->dof_vel, sizeof(double) * N * 18);
+  if (actions) for (int i = 0; i < N * 18; i++) actions[i] = e->actions[i];
+  if (commands) memcpy(commands, e->commands, sizeof(double) * N * 3);
+  if (ep_len) memcpy(ep_len, e->ep_len, sizeof(int64_t) * N);
+  if (episode_sums) memcpy(episode_sums, e->episode_sums, sizeof(double) * NMO_NREW * N);
+}
+void nmo_env_set_buffers(nmo_env* e, const double* dof_pos, const double* dof_vel, const double* actions, const double* commands,
+                         const int64_t* ep_len, const double* episode_sums) {
+  int N = e->N;
+  if (dof_pos) memcpy(e->dof_pos, dof_pos, sizeof(double) * N * 18);
+  if (dof_vel) memcpy(e->dof_vel, dof_vel, sizeof(double) * N * 18);
+  if (actions) for (int i = 0; i < N * 18; i++) e->actions[i] = (float)actions[i];
+  if (commands) memcpy(e->commands, commands, sizeof(double) * N * 3);
+  if (ep_len) memcpy(e->ep_len, ep_len, sizeof(int64_t) * N);
+  if (episode_sums) memcpy(e->episode_sums, episode_sums, sizeof(double) * NMO_NREW * N);
+}
+int nmo_env_episode_stats(nmo_env* e, double* out8) {
+  memcpy(out8, e->ep_stats, sizeof e->ep_stats);
+  return e->last_nreset;
+}
+void nmo_env_get_debug(nmo_env* e, double* blv, double* bav, double* pg, double* tibia, double* feet, double* body, double* rt) {
+  int N = e->N;
+  if (blv) memcpy(blv, e->blv, sizeof(double) * N * 3);
+  if (bav) memcpy(bav, e->bav, sizeof(double) * N * 3);
+  if (pg) memcpy(pg, e->pg, sizeof(double) * N * 3);
+  if (tibia) memcpy(tibia, e->tibia, sizeof(double) * N * 6);
+  if (feet) memcpy(feet, e->feet, sizeof(double) * N * 6);
+  if (body) memcpy(body, e->body, sizeof(double) * N);
+  if (rt) memcpy(rt, e->rew_terms, sizeof(double) * NMO_NREW * N);
+}

@@ -1,0 +1,646 @@
+/* nm_oracle_physics.c - fp64 restatement of mj_step for the Nightmare-v3 model class.
+ *
+ * TEST INFRASTRUCTURE ONLY (see nm_oracle.h). Restates, stage by stage, what MuJoCo 3.1.2 executes
+ * for `mj_step(model, data, nstep)` as called at reference envs/nightmare_v3_env.py:200 on the model
+ * of reference models/nightmare_v3/mjmodel.xml (free joint + 18 hinges, 18 velocity servos, mesh-vs-plane
+ * contacts, pyramidal cones, PGS x3 + noslip x4, implicitfast; mjmodel.xml:2-3). MuJoCo itself is a
+ * third-party dependency absent from /root/reference; function names below are the upstream stages
+ * restated. PARITY UNPINNED against MuJoCo (see header).
+ */
+#include "nm_oracle.h"
+
+#include <math.h>
+#include <string.h>
+
+#include "../nightmare_rl_amd/model/nm_model_data.h"
+
+#define NB NMO_NBODY
+#define NV NMO_NV
+#define NU NMO_NU
+#define MJ_MINVAL 1e-15
+#define MJ_MAXVAL 1e10
+#define TOL_PLANEMESH 0.3 /* engine_collision_convex.c: extra plane-mesh points at least this * rbound from the first */
+
+static int g_collide_self = 0;
+void nmo_set_collide_self(int on) { g_collide_self = on; }
+int nmo_sizeof_data(void) { return (int)sizeof(nmo_data); }
+int nmo_sizeof_scratch(void) { return (int)sizeof(nmo_scratch); }
+
+/* ------------------------------------------------------------------ small math (engine_util_blas / _spatial) */
+static double dot3(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static double normalize3(double* v) {
+  double n = sqrt(dot3(v, v));
+  if (n < MJ_MINVAL) { v[0] = 1; v[1] = 0; v[2] = 0; return 0; }
+  v[0] /= n; v[1] /= n; v[2] /= n;
+  return n;
+}
+static void normalize4(double* q) {
+  double n = sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  if (n < MJ_MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  q[0] /= n; q[1] /= n; q[2] /= n; q[3] /= n;
+}
+static void mulQuat(double* r, const double* a, const double* b) {
+  double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3], a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                 a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1], a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(r, t, sizeof t);
+}
+static void quat2Mat(double* m, const double* q) {
+  double q00 = q[0] * q[0], q01 = q[0] * q[1], q02 = q[0] * q[2], q03 = q[0] * q[3], q11 = q[1] * q[1], q12 = q[1] * q[2],
+         q13 = q[1] * q[3], q22 = q[2] * q[2], q23 = q[2] * q[3], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2 * (q12 - q03); m[2] = 2 * (q13 + q02); m[3] = 2 * (q12 + q03);
+  m[5] = 2 * (q23 - q01); m[6] = 2 * (q13 - q02); m[7] = 2 * (q23 + q01);
+}
+static void mulMatVec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2],
+         z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void mulMatTVec3(double* r, const double* m, const double* v) {
+  double x = m[0] * v[0] + m[3] * v[1] + m[6] * v[2], y = m[1] * v[0] + m[4] * v[1] + m[7] * v[2],
+         z = m[2] * v[0] + m[5] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void axisAngle2Quat(double* q, const double* axis, double angle) {
+  if (angle == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+/* spatial inertia (10 numbers: Ixx Iyy Izz Ixy Ixz Iyz, m*d, m) times motion vector [ang; lin] */
+static void mulInertVec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+static void crossMotion(double* r, const double* vel, const double* v) {
+  double a[3], b[3], c[3];
+  cross3(a, vel, v);          /* w x v_ang */
+  cross3(b, vel, v + 3);      /* w x v_lin */
+  cross3(c, vel + 3, v);      /* vel_lin x v_ang */
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2];
+  r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+static void crossForce(double* r, const double* vel, const double* f) {
+  double a[3], b[3], c[3];
+  cross3(a, vel, f);          /* w x torque */
+  cross3(b, vel + 3, f + 3);  /* v x force */
+  cross3(c, vel, f + 3);      /* w x force */
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2];
+  r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+
+/* tree helpers: dof parent (dof_parentid), dof body */
+static int dof_parent(int i) {
+  if (i < 6) return i - 1;
+  return ((i - 6) % 3 == 0) ? 5 : i - 1;
+}
+static int dof_body(int i) { return i < 6 ? 1 : 2 + (i - 6); }
+
+/* ------------------------------------------------------------------ mj_resetData */
+void nmo_reset_data(nmo_data* d) {
+  int nw = d->nwarning;
+  memset(d, 0, sizeof *d);
+  d->nwarning = nw;
+  for (int i = 0; i < NMO_NQ; i++) d->qpos[i] = nm_qpos0[i];
+}
+
+/* ------------------------------------------------------------------ P1: mj_kinematics (engine_core_smooth.c) */
+static void kinematics(nmo_data* d) {
+  memset(d->xpos[0], 0, sizeof d->xpos[0]);
+  d->xquat[0][0] = 1; d->xquat[0][1] = d->xquat[0][2] = d->xquat[0][3] = 0;
+  quat2Mat(d->xmat[0], d->xquat[0]);
+  normalize4(d->qpos + 3); /* mj_normalizeQuat on qpos */
+  for (int b = 1; b < NB; b++) {
+    if (b == 1) { /* free joint */
+      memcpy(d->xpos[1], d->qpos, 3 * sizeof(double));
+      memcpy(d->xquat[1], d->qpos + 3, 4 * sizeof(double));
+    } else {
+      int p = nm_body_parent[b], j = b - 2;
+      double v[3], qloc[4];
+      mulMatVec3(v, d->xmat[p], nm_body_pos[b]);
+      for (int k = 0; k < 3; k++) d->xpos[b][k] = d->xpos[p][k] + v[k];
+      mulQuat(d->xquat[b], d->xquat[p], nm_body_quat[b]);
+      /* joint axis / anchor in the global frame (jnt_pos = 0 -> anchor = body origin) */
+      double m[9];
+      quat2Mat(m, d->xquat[b]);
+      mulMatVec3(d->xaxis[j], m, nm_jnt_axis[j]);
+      memcpy(d->xanchor[j], d->xpos[b], 3 * sizeof(double));
+      axisAngle2Quat(qloc, nm_jnt_axis[j], d->qpos[7 + j] - nm_qpos0[7 + j]);
+      mulQuat(d->xquat[b], d->xquat[b], qloc);
+    }
+    normalize4(d->xquat[b]);
+    quat2Mat(d->xmat[b], d->xquat[b]);
+  }
+  for (int b = 1; b < NB; b++) { /* inertial frames */
+    double v[3], q[4];
+    mulMatVec3(v, d->xmat[b], nm_body_ipos[b]);
+    for (int k = 0; k < 3; k++) d->xipos[b][k] = d->xpos[b][k] + v[k];
+    mulQuat(q, d->xquat[b], nm_body_iquat[b]);
+    quat2Mat(d->ximat[b], q);
+  }
+}
+
+/* ------------------------------------------------------------------ P1: mj_comPos */
+static void comPos(nmo_data* d) {
+  double com[3] = {0, 0, 0}, mass = 0;
+  for (int b = NB - 1; b >= 1; b--) {
+    for (int k = 0; k < 3; k++) com[k] += nm_body_mass[b] * d->xipos[b][k];
+    mass += nm_body_mass[b];
+  }
+  for (int k = 0; k < 3; k++) d->subtree_com[k] = com[k] / mass;
+  memset(d->cinert[0], 0, sizeof d->cinert[0]);
+  for (int b = 1; b < NB; b++) { /* mju_inertCom */
+    double dif[3], tmp[9], rot[9];
+    const double* mat = d->ximat[b];
+    const double* in = nm_body_inertia[b];
+    double m = nm_body_mass[b];
+    for (int k = 0; k < 3; k++) dif[k] = d->xipos[b][k] - d->subtree_com[k];
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) tmp[3 * i + j] = in[i] * mat[3 * j + i]; /* diag(I) * mat' */
+    for (int i = 0; i < 3; i++)
+      for (int j = 0; j < 3; j++) rot[3 * i + j] = mat[3 * i] * tmp[j] + mat[3 * i + 1] * tmp[3 + j] + mat[3 * i + 2] * tmp[6 + j];
+    double* r = d->cinert[b];
+    r[0] = rot[0] + m * (dif[1] * dif[1] + dif[2] * dif[2]);
+    r[1] = rot[4] + m * (dif[0] * dif[0] + dif[2] * dif[2]);
+    r[2] = rot[8] + m * (dif[0] * dif[0] + dif[1] * dif[1]);
+    r[3] = rot[1] - m * dif[0] * dif[1];
+    r[4] = rot[2] - m * dif[0] * dif[2];
+    r[5] = rot[5] - m * dif[1] * dif[2];
+    r[6] = m * dif[0]; r[7] = m * dif[1]; r[8] = m * dif[2];
+    r[9] = m;
+  }
+  /* cdof: free joint - translations in the global frame, rotations about the body axes */
+  double off[3];
+  for (int k = 0; k < 3; k++) off[k] = d->subtree_com[k] - d->xpos[1][k];
+  for (int i = 0; i < 3; i++) {
+    memset(d->cdof[i], 0, sizeof d->cdof[i]);
+    d->cdof[i][3 + i] = 1;
+    double ax[3] = {d->xmat[1][i], d->xmat[1][3 + i], d->xmat[1][6 + i]};
+    memcpy(d->cdof[3 + i], ax, sizeof ax);
+    cross3(d->cdof[3 + i] + 3, ax, off);
+  }
+  for (int j = 0; j < NU; j++) {
+    for (int k = 0; k < 3; k++) off[k] = d->subtree_com[k] - d->xanchor[j][k];
+    memcpy(d->cdof[6 + j], d->xaxis[j], 3 * sizeof(double));
+    cross3(d->cdof[6 + j] + 3, d->xaxis[j], off);
+  }
+}
+
+/* ------------------------------------------------------------------ P2: mj_crb + mj_factorM */
+static void crb(nmo_data* d) {
+  double c[NB][10];
+  memcpy(c, d->cinert, sizeof c);
+  for (int b = NB - 1; b >= 1; b--) {
+    int p = nm_body_parent[b];
+    if (p > 0)
+      for (int k = 0; k < 10; k++) c[p][k] += c[b][k];
+  }
+  memset(d->qM, 0, sizeof d->qM);
+  for (int i = 0; i < NV; i++) {
+    double buf[6];
+    mulInertVec(buf, c[dof_body(i)], d->cdof[i]);
+    for (int j = i; j >= 0; j = dof_parent(j)) {
+      double s = 0;
+      for (int k = 0; k < 6; k++) s += d->cdof[j][k] * buf[k];
+      d->qM[i][j] = d->qM[j][i] = s;
+    }
+  }
+}
+
+/* L'DL factorisation in mj_factorM's order: k from the last dof up, updating ancestor rows */
+static void factorLD(double LD[NV][NV], double* diaginv) {
+  for (int k = NV - 1; k >= 0; k--) {
+    for (int i = dof_parent(k); i >= 0; i = dof_parent(i)) {
+      double tmp = LD[k][i] / LD[k][k];
+      for (int j = i; j >= 0; j = dof_parent(j)) LD[i][j] -= LD[k][j] * tmp;
+      LD[k][i] = tmp;
+    }
+    diaginv[k] = 1.0 / LD[k][k];
+  }
+}
+static void solveLD(const double LD[NV][NV], const double* diaginv, double* x) { /* mj_solveLD */
+  for (int i = NV - 1; i >= 0; i--)
+    if (x[i] != 0)
+      for (int j = dof_parent(i); j >= 0; j = dof_parent(j)) x[j] -= LD[i][j] * x[i];
+  for (int i = 0; i < NV; i++) x[i] *= diaginv[i];
+  for (int i = 0; i < NV; i++)
+    for (int j = dof_parent(i); j >= 0; j = dof_parent(j)) x[i] -= LD[i][j] * x[j];
+}
+static void solveM2(const nmo_data* d, double* x) { /* mj_solveM2: x <- sqrt(inv(D)) * inv(L') * x */
+  for (int i = NV - 1; i >= 0; i--)
+    if (x[i] != 0)
+      for (int j = dof_parent(i); j >= 0; j = dof_parent(j)) x[j] -= d->qLD[i][j] * x[i];
+  for (int i = 0; i < NV; i++) x[i] *= sqrt(d->qLDiagInv[i]);
+}
+static void factorM(nmo_data* d) {
+  memcpy(d->qLD, d->qM, sizeof d->qM);
+  factorLD(d->qLD, d->qLDiagInv);
+}
+
+/* ------------------------------------------------------------------ P5: mj_collision (plane vs convex mesh) */
+static void make_frame(double* f) { /* mju_makeFrame: f[0:3] normal given, f[3:6] zero */
+  normalize3(f);
+  f[3] = f[4] = f[5] = 0;
+  if (f[1] < 0.5 && f[1] > -0.5) f[4] = 1; else f[5] = 1;
+  double t = dot3(f, f + 3);
+  for (int k = 0; k < 3; k++) f[3 + k] -= t * f[k];
+  normalize3(f + 3);
+  cross3(f + 6, f, f + 3);
+}
+static void add_contact(nmo_data* d, const double* pos, const double* normal, double dist, int body, int geom) {
+  if (d->ncon >= NMO_MAXCON) return;
+  int c = d->ncon++;
+  memcpy(d->con_pos[c], pos, 3 * sizeof(double));
+  memcpy(d->con_frame[c], normal, 3 * sizeof(double));
+  make_frame(d->con_frame[c]);
+  d->con_dist[c] = dist;
+  d->con_body[c] = body;
+  d->con_geom[c] = geom;
+}
+/* mjc_PlaneConvex for the floor (z = 0, normal +z, mjmodel.xml:32) against hull g of body b */
+static void plane_convex(nmo_data* d, int g) {
+  const double normal[3] = {0, 0, 1};
+  int b = nm_col_body[g], nvert = nm_col_nvert[g], vadr = nm_col_vadr[g];
+  const double* mat = d->xmat[b];
+  const double* pos = d->xpos[b];
+  /* bounding-sphere prefilter (mj_collideGeoms plane case): centre height - rbound > margin(0) -> no contact */
+  double cen[3];
+  mulMatVec3(cen, mat, nm_col_center[g]);
+  if (cen[2] + pos[2] - nm_col_rbound[g] > 0) return;
+  /* support point along -normal, in the mesh's local frame */
+  double locdir[3], neg[3] = {0, 0, -1};
+  mulMatTVec3(locdir, mat, neg);
+  int ibest = 0;
+  double best = -1e300;
+  for (int i = 0; i < nvert; i++) {
+    double v = dot3(locdir, nm_hull_vert[vadr + i]);
+    if (v > best) { best = v; ibest = i; }
+  }
+  double vec[3];
+  mulMatVec3(vec, mat, nm_hull_vert[vadr + ibest]);
+  for (int k = 0; k < 3; k++) vec[k] += pos[k];
+  double dist = vec[2];
+  if (dist >= 0) return; /* dist >= includemargin (0): contact excluded ('in gap') */
+  double first[3] = {vec[0], vec[1], vec[2] - 0.5 * dist};
+  add_contact(d, first, normal, dist, b, g);
+  int cnt = 1;
+  /* up to 3 more penetrating hull neighbours of the support vertex, >= tolerance away from the first contact */
+  double tolerance = TOL_PLANEMESH * nm_col_rbound[g];
+  double threshold; /* plane point (origin) in the mesh frame, margin 0: dot(locdir, v) > threshold <=> vertex below the plane */
+  {
+    double dif[3] = {-pos[0], -pos[1], -pos[2]}, loc[3];
+    mulMatTVec3(loc, mat, dif);
+    threshold = dot3(locdir, loc);
+  }
+  for (int e = 0; e < NM_HULL_MAXNBR && cnt < 4; e++) {
+    int nb = nm_hull_nbr[vadr + ibest][e];
+    if (nb < 0) break;
+    const double* v = nm_hull_vert[vadr + nb];
+    if (dot3(locdir, v) > threshold) {
+      double pnt[3];
+      mulMatVec3(pnt, mat, v);
+      for (int k = 0; k < 3; k++) pnt[k] += pos[k];
+      double dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
+      if (sqrt(dot3(dd, dd)) < tolerance) continue;
+      double cd = pnt[2];
+      double cp[3] = {pnt[0], pnt[1], pnt[2] - 0.5 * cd};
+      add_contact(d, cp, normal, cd, b, g);
+      cnt++;
+    }
+  }
+}
+static void collision(nmo_data* d) {
+  d->ncon = 0;
+  for (int g = 0; g < NM_NCOL; g++) plane_convex(d, g);
+  (void)g_collide_self; /* tibia-tibia convex pairs: see DESIGN.md (not generated in this round) */
+}
+
+/* ------------------------------------------------------------------ P6: mj_makeConstraint (+ impedance, diagApprox) */
+static void jac_point(const nmo_data* d, double jacp[3][NV], int body, const double* point) { /* mj_jac, translational */
+  double off[3];
+  for (int k = 0; k < 3; k++) off[k] = point[k] - d->subtree_com[k];
+  memset(jacp, 0, 3 * NV * sizeof(double));
+  int i = (body == 1) ? 5 : 6 + (body - 2);
+  for (; i >= 0; i = dof_parent(i)) {
+    double t[3];
+    cross3(t, d->cdof[i], off);
+    for (int k = 0; k < 3; k++) jacp[k][i] = t[k] + d->cdof[i][3 + k];
+  }
+}
+static double impedance(double pos) { /* getimpedance with margin 0 */
+  const double* si = nm_solimp;
+  double x = fabs(pos / si[2]);
+  if (x >= 1) return si[1];
+  if (x <= 0) return si[0];
+  double p = si[4], mid = si[3], y;
+  if (p == 1) y = x;
+  else if (x <= mid) y = pow(x, p) / pow(mid, p - 1);
+  else y = 1 - pow(1 - x, p) / pow(1 - mid, p - 1);
+  return si[0] + y * (si[1] - si[0]);
+}
+static void make_constraint(nmo_data* d, nmo_scratch* s) {
+  int n = 0;
+  const double mu = NM_FRICTION;
+  for (int c = 0; c < d->ncon; c++) {
+    double jp[3][NV], jf[3][NV];
+    jac_point(d, jp, d->con_body[c], d->con_pos[c]);
+    const double* fr = d->con_frame[c];
+    for (int r = 0; r < 3; r++)
+      for (int i = 0; i < NV; i++) jf[r][i] = fr[3 * r] * jp[0][i] + fr[3 * r + 1] * jp[1][i] + fr[3 * r + 2] * jp[2][i];
+    /* pyramidal cone, condim 3: rows n + mu t1, n - mu t1, n + mu t2, n - mu t2 (mj_instantiateContact) */
+    double tran = nm_body_invweight0[d->con_body[c]][0]; /* + world (0) */
+    double imp = impedance(d->con_dist[c]);
+    double dA = tran + mu * mu * tran; /* mj_diagApprox, pyramidal */
+    double R = (1 - imp) * dA / imp;
+    if (R < MJ_MINVAL) R = MJ_MINVAL;
+    double Rpy = 2 * mu * mu * R;
+    double dmax = nm_solimp[1], tc = nm_solref[0], dr = nm_solref[1];
+    double K = 1 / fmax(MJ_MINVAL, dmax * dmax * tc * tc * dr * dr), B = 2 / fmax(MJ_MINVAL, dmax * tc);
+    for (int k = 1; k < 3; k++)
+      for (int sgn = 0; sgn < 2; sgn++) {
+        for (int i = 0; i < NV; i++) s->J[n][i] = jf[0][i] + (sgn ? -mu : mu) * jf[k][i];
+        s->pos[n] = d->con_dist[c];
+        s->diagApprox[n] = dA;
+        s->R[n] = Rpy;
+        s->D[n] = 1 / Rpy;
+        s->K[n] = K; s->B[n] = B; s->imp[n] = imp;
+        n++;
+      }
+  }
+  d->nefc = n;
+}
+/* mj_projectConstraint (dense): AR = J inv(M) J' + diag(R) through JM2 = J inv(L') sqrt(inv(D)) */
+static void project_constraint(nmo_data* d, nmo_scratch* s) {
+  int n = d->nefc;
+  for (int i = 0; i < n; i++) {
+    memcpy(s->JM2[i], s->J[i], sizeof s->J[i]);
+    solveM2(d, s->JM2[i]);
+  }
+  for (int i = 0; i < n; i++)
+    for (int j = 0; j <= i; j++) {
+      double a = 0;
+      for (int k = 0; k < NV; k++) a += s->JM2[i][k] * s->JM2[j][k];
+      s->AR[i * n + j] = s->AR[j * n + i] = a;
+    }
+  for (int i = 0; i < n; i++) s->AR[i * n + i] += s->R[i];
+}
+
+/* ------------------------------------------------------------------ P3: mj_comVel + mj_rne */
+static void comVel(nmo_data* d) {
+  memset(d->cvel[0], 0, sizeof d->cvel[0]);
+  /* body 1: free joint. translations first (cdof_dot = 0), then the three rotations from the same velocity */
+  double cv[6] = {0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 3; i++) {
+    memset(d->cdof_dot[i], 0, sizeof d->cdof_dot[i]);
+    for (int k = 0; k < 6; k++) cv[k] += d->cdof[i][k] * d->qvel[i];
+  }
+  for (int i = 3; i < 6; i++) crossMotion(d->cdof_dot[i], cv, d->cdof[i]);
+  for (int i = 3; i < 6; i++)
+    for (int k = 0; k < 6; k++) cv[k] += d->cdof[i][k] * d->qvel[i];
+  memcpy(d->cvel[1], cv, sizeof cv);
+  for (int b = 2; b < NB; b++) {
+    int i = 6 + (b - 2);
+    memcpy(cv, d->cvel[nm_body_parent[b]], sizeof cv);
+    crossMotion(d->cdof_dot[i], cv, d->cdof[i]);
+    for (int k = 0; k < 6; k++) cv[k] += d->cdof[i][k] * d->qvel[i];
+    memcpy(d->cvel[b], cv, sizeof cv);
+  }
+}
+static void rne(nmo_data* d) { /* mj_rne(flg_acc = 0) -> qfrc_bias */
+  double cacc[NB][6], cfrc[NB][6];
+  memset(cacc, 0, sizeof cacc);
+  for (int k = 0; k < 3; k++) cacc[0][3 + k] = -nm_gravity[k];
+  memset(cfrc[0], 0, sizeof cfrc[0]);
+  for (int b = 1; b < NB; b++) {
+    int p = nm_body_parent[b];
+    int d0 = (b == 1) ? 0 : 6 + (b - 2), dn = (b == 1) ? 6 : 1;
+    memcpy(cacc[b], cacc[p], sizeof cacc[b]);
+    for (int i = d0; i < d0 + dn; i++)
+      for (int k = 0; k < 6; k++) cacc[b][k] += d->cdof_dot[i][k] * d->qvel[i];
+    double t1[6], t2[6], t3[6];
+    mulInertVec(t1, d->cinert[b], cacc[b]);
+    mulInertVec(t2, d->cinert[b], d->cvel[b]);
+    crossForce(t3, d->cvel[b], t2);
+    for (int k = 0; k < 6; k++) cfrc[b][k] = t1[k] + t3[k];
+  }
+  for (int b = NB - 1; b >= 2; b--)
+    for (int k = 0; k < 6; k++) cfrc[nm_body_parent[b]][k] += cfrc[b][k];
+  for (int i = 0; i < NV; i++) {
+    double sum = 0;
+    const double* f = cfrc[dof_body(i)];
+    for (int k = 0; k < 6; k++) sum += d->cdof[i][k] * f[k];
+    d->qfrc_bias[i] = sum;
+  }
+}
+
+/* ------------------------------------------------------------------ P4: mj_fwdActuation, mj_fwdAcceleration */
+static void fwd_actuation(nmo_data* d) {
+  memset(d->qfrc_actuator, 0, sizeof d->qfrc_actuator);
+  for (int j = 0; j < NU; j++) {
+    double c = d->ctrl[j];
+    if (c > NM_CTRL_MAX) c = NM_CTRL_MAX;
+    if (c < -NM_CTRL_MAX) c = -NM_CTRL_MAX;
+    d->qfrc_actuator[6 + j] = NM_KV * c - NM_KV * d->qvel[6 + j]; /* gain*ctrl + biasprm[2]*velocity */
+  }
+}
+static void fwd_acceleration(nmo_data* d) {
+  for (int i = 0; i < NV; i++) d->qfrc_smooth[i] = -d->qfrc_bias[i] + d->qfrc_actuator[i]; /* passive, applied = 0 */
+  memcpy(d->qacc_smooth, d->qfrc_smooth, sizeof d->qacc_smooth);
+  solveLD(d->qLD, d->qLDiagInv, d->qacc_smooth);
+}
+
+/* ------------------------------------------------------------------ P7: mj_fwdConstraint: warmstart, PGS, NoSlip */
+static void dual_finish(nmo_data* d, nmo_scratch* s) { /* qfrc_constraint = J' f ; qacc = qacc_smooth + inv(M) qfrc_constraint */
+  int n = d->nefc;
+  for (int k = 0; k < NV; k++) {
+    double a = 0;
+    for (int i = 0; i < n; i++) a += s->J[i][k] * d->efc_force[i];
+    d->qfrc_constraint[k] = a;
+  }
+  double t[NV];
+  memcpy(t, d->qfrc_constraint, sizeof t);
+  solveLD(d->qLD, d->qLDiagInv, t);
+  for (int k = 0; k < NV; k++) d->qacc[k] = d->qacc_smooth[k] + t[k];
+}
+static double residual(const nmo_data* d, const nmo_scratch* s, int i, int subR) {
+  int n = d->nefc;
+  double r = s->b[i];
+  for (int j = 0; j < n; j++) r += s->AR[i * n + j] * d->efc_force[j];
+  if (subR) r -= s->R[i] * d->efc_force[i];
+  return r;
+}
+static void fwd_constraint(nmo_data* d, nmo_scratch* s) {
+  int n = d->nefc;
+  d->solver_niter = d->noslip_niter = 0;
+  if (n == 0) {
+    memcpy(d->qacc, d->qacc_smooth, sizeof d->qacc);
+    memset(d->qfrc_constraint, 0, sizeof d->qfrc_constraint);
+    return;
+  }
+  /* mj_referenceConstraint: aref = -B vel - K imp (pos - margin); b = J qacc_smooth - aref */
+  for (int i = 0; i < n; i++) {
+    double v = 0, a = 0;
+    for (int k = 0; k < NV; k++) { v += s->J[i][k] * d->qvel[k]; a += s->J[i][k] * d->qacc_smooth[k]; }
+    s->vel[i] = v;
+    s->aref[i] = -s->B[i] * v - s->K[i] * s->imp[i] * s->pos[i];
+    s->b[i] = a - s->aref[i];
+  }
+  /* warmstart (PGS branch): forces from qacc_warmstart, keep only if the dual cost is below that of zero */
+  double cost = 0;
+  for (int i = 0; i < n; i++) {
+    double jar = -s->aref[i];
+    for (int k = 0; k < NV; k++) jar += s->J[i][k] * d->qacc_warmstart[k];
+    d->efc_force[i] = jar < 0 ? -s->D[i] * jar : 0; /* mj_constraintUpdate, inequality rows */
+  }
+  for (int i = 0; i < n; i++) {
+    double a = 0;
+    for (int j = 0; j < n; j++) a += s->AR[i * n + j] * d->efc_force[j];
+    cost += d->efc_force[i] * s->b[i] + 0.5 * d->efc_force[i] * a;
+  }
+  if (cost > 0) memset(d->efc_force, 0, n * sizeof(double));
+  const double scale = 1.0 / (NM_MEANINERTIA * NV);
+  /* mj_solPGS */
+  for (int iter = 0; iter < NM_ITERATIONS; iter++) {
+    double improvement = 0;
+    for (int i = 0; i < n; i++) {
+      double res = residual(d, s, i, 0), old = d->efc_force[i];
+      double f = old - res * (1.0 / s->AR[i * n + i]); /* ARinv precomputed upstream */
+      if (f < 0) f = 0;
+      double delta = f - old, change = 0.5 * delta * delta * s->AR[i * n + i] + delta * res;
+      if (change > 1e-10) { f = old; change = 0; }
+      d->efc_force[i] = f;
+      improvement -= change;
+    }
+    improvement *= scale;
+    d->solver_niter++;
+    if (improvement < NM_TOLERANCE) break;
+  }
+  /* mj_solNoSlip: friction directions of each pyramid pair without the regulariser R */
+  for (int iter = 0; iter < NM_NOSLIP_ITERATIONS; iter++) {
+    double improvement = 0;
+    if (iter == 0)
+      for (int i = 0; i < n; i++) improvement += 0.5 * d->efc_force[i] * d->efc_force[i] * s->R[i];
+    for (int j = 0; j < n; j += 2) {
+      double Ac[4] = {s->AR[j * n + j] - s->R[j], s->AR[j * n + j + 1], s->AR[(j + 1) * n + j], s->AR[(j + 1) * n + j + 1] - s->R[j + 1]};
+      double res[2] = {residual(d, s, j, 1), residual(d, s, j + 1, 1)};
+      double old[2] = {d->efc_force[j], d->efc_force[j + 1]};
+      double bc[2] = {res[0] - Ac[0] * old[0] - Ac[1] * old[1], res[1] - Ac[2] * old[0] - Ac[3] * old[1]};
+      double mid = 0.5 * (old[0] + old[1]);
+      double K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid * (Ac[0] - Ac[3]) + bc[0] - bc[1];
+      double f[2];
+      if (K1 < MJ_MINVAL) { f[0] = f[1] = mid; }
+      else {
+        double y = -K0 / K1;
+        if (y < -mid) { f[0] = 0; f[1] = 2 * mid; }
+        else if (y > mid) { f[0] = 2 * mid; f[1] = 0; }
+        else { f[0] = mid + y; f[1] = mid - y; }
+      }
+      double dl[2] = {f[0] - old[0], f[1] - old[1]};
+      double change = 0.5 * (dl[0] * (Ac[0] * dl[0] + Ac[1] * dl[1]) + dl[1] * (Ac[2] * dl[0] + Ac[3] * dl[1])) + dl[0] * res[0] + dl[1] * res[1];
+      if (change > 1e-10) { f[0] = old[0]; f[1] = old[1]; change = 0; }
+      d->efc_force[j] = f[0]; d->efc_force[j + 1] = f[1];
+      improvement -= change;
+    }
+    improvement *= scale;
+    d->noslip_niter++;
+    if (improvement < NM_NOSLIP_TOLERANCE) break;
+  }
+  dual_finish(d, s);
+}
+
+/* ------------------------------------------------------------------ P8: touch sensors (mj_sensorAcc) */
+static double ray_sphere(const double* center, double radius, const double* pnt, const double* vec) { /* mju_rayGeom, sphere */
+  double dif[3] = {pnt[0] - center[0], pnt[1] - center[1], pnt[2] - center[2]};
+  double a = dot3(vec, vec), b = dot3(vec, dif), c = dot3(dif, dif) - radius * radius;
+  double det = b * b - a * c;
+  if (det < MJ_MINVAL || a < MJ_MINVAL) return -1;
+  det = sqrt(det);
+  double x0 = (-b - det) / a, x1 = (-b + det) / a;
+  if (x0 >= 0) return x0;
+  if (x1 >= 0) return x1;
+  return -1;
+}
+static void sensor_touch(nmo_data* d) {
+  for (int sidx = 0; sidx < NMO_NSENS; sidx++) {
+    int b = nm_sens_body[sidx];
+    double sp[3];
+    mulMatVec3(sp, d->xmat[b], nm_sens_pos[sidx]);
+    for (int k = 0; k < 3; k++) sp[k] += d->xpos[b][k];
+    double sum = 0;
+    for (int c = 0; c < d->ncon; c++) {
+      if (d->con_body[c] != b) continue; /* body1 is always the world here */
+      const double* f = d->efc_force + 4 * c;
+      double normal = f[0] + f[1] + f[2] + f[3]; /* mj_contactForce, pyramidal: normal = sum of edge forces */
+      if (normal <= 0) continue;
+      double ray[3] = {d->con_frame[c][0] * normal, d->con_frame[c][1] * normal, d->con_frame[c][2] * normal};
+      normalize3(ray);
+      for (int k = 0; k < 3; k++) ray[k] = -ray[k]; /* sensor body is geom2's body */
+      if (ray_sphere(sp, nm_sens_radius[sidx], d->con_pos[c], ray) >= 0) sum += normal;
+    }
+    d->sensordata[sidx] = sum;
+  }
+}
+
+/* ------------------------------------------------------------------ mj_forward */
+void nmo_forward(nmo_data* d, nmo_scratch* s) {
+  kinematics(d);
+  comPos(d);
+  crb(d);
+  factorM(d);
+  collision(d);
+  make_constraint(d, s);
+  project_constraint(d, s);
+  comVel(d);
+  rne(d);
+  fwd_actuation(d);
+  fwd_acceleration(d);
+  fwd_constraint(d, s);
+  sensor_touch(d);
+}
+
+/* ------------------------------------------------------------------ P9: mj_implicit (implicitfast) + mj_advance */
+static int is_bad(double x) { return isnan(x) || x > MJ_MAXVAL || x < -MJ_MAXVAL; }
+static void integrate(nmo_data* d) {
+  const double h = NM_TIMESTEP;
+  /* (M - h dF/dv) qacc = qfrc_smooth + qfrc_constraint ; dF/dv = -kv on the 18 actuated dofs (mjd_smooth_vel) */
+  double H[NV][NV], Hinv[NV], qacc[NV];
+  memcpy(H, d->qM, sizeof H);
+  for (int j = 0; j < NU; j++) H[6 + j][6 + j] += h * NM_KV;
+  factorLD(H, Hinv);
+  for (int i = 0; i < NV; i++) qacc[i] = d->qfrc_smooth[i] + d->qfrc_constraint[i];
+  solveLD((const double(*)[NV])H, Hinv, qacc);
+  /* mj_advance */
+  for (int i = 0; i < NV; i++) d->qvel[i] += h * qacc[i];
+  for (int k = 0; k < 3; k++) d->qpos[k] += h * d->qvel[k];
+  { /* mju_quatIntegrate: q <- q * exp(h w), w in the body frame */
+    double ax[3] = {d->qvel[3], d->qvel[4], d->qvel[5]}, qr[4];
+    double ang = h * normalize3(ax);
+    axisAngle2Quat(qr, ax, ang);
+    normalize4(d->qpos + 3);
+    mulQuat(d->qpos + 3, d->qpos + 3, qr);
+  }
+  for (int j = 0; j < NU; j++) d->qpos[7 + j] += h * d->qvel[6 + j];
+  d->time += h;
+  memcpy(d->qacc_warmstart, d->qacc, sizeof d->qacc);
+}
+
+void nmo_step(nmo_data* d, nmo_scratch* s, int nstep) {
+  for (int it = 0; it < nstep; it++) {
+    int bad = 0; /* mj_checkPos / mj_checkVel */
+    for (int i = 0; i < NMO_NQ; i++) bad |= is_bad(d->qpos[i]);
+    for (int i = 0; i < NV; i++) bad |= is_bad(d->qvel[i]);
+    if (bad) { d->nwarning++; nmo_reset_data(d); }
+    nmo_forward(d, s);
+    bad = 0; /* mj_checkAcc */
+    for (int i = 0; i < NV; i++) bad |= is_bad(d->qacc[i]);
+    if (bad) { d->nwarning++; nmo_reset_data(d); nmo_forward(d, s); }
+    integrate(d);
+  }
+}

@@ -1,0 +1,70 @@
+"""The oracle's env layer (oracle/nm_oracle_env.c) against golden vectors produced by the
+reference's own NightmareV3Env class (tests/golden/make_goldens.py)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz"]
+
+
+def replay(orc, g, check):
+    N = g["actions"].shape[1]
+    env = orc.OracleEnv(N, seed=0)
+    env.reset_idx(None, cmd_u=g["reset_u"])
+    env.set_state(g["init_qpos"], g["init_qvel"], g["init_qacc_warmstart"])
+    env.set_buffers(dof_pos=g["init_dof_pos"], dof_vel=g["init_dof_vel"], commands=g["init_commands"], ep_len=g["init_ep_len"])
+    for t in range(g["actions"].shape[0]):
+        obs, rew, done, to = env.step(g["actions"][t], cmd_u=g["cmd_u"][t])
+        check(t, env, obs, rew, done, to)
+    return env
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_env_layer_matches_reference(oracle_mod, name):
+    g = load_golden(name)
+
+    def check(t, env, obs, rew, done, to):
+        np.testing.assert_array_equal(done, g["done"][t], err_msg=f"done t={t}")
+        np.testing.assert_array_equal(to, g["time_outs"][t], err_msg=f"time_outs t={t}")
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=0, atol=2e-7, err_msg=f"obs t={t}")
+        np.testing.assert_allclose(rew, g["rew"][t], rtol=1e-6, atol=1e-7, err_msg=f"rew t={t}")
+        b = env.get_buffers()
+        np.testing.assert_allclose(b["commands"], g["commands"][t], atol=1e-15)
+        np.testing.assert_array_equal(b["ep_len"], g["ep_len"][t])
+        order = [list(g["reward_names"]).index(k) for k in oracle_mod.REW_NAMES]  # reference dict order -> oracle order
+        np.testing.assert_allclose(b["episode_sums"], g["episode_sums"][t][order], rtol=5e-7, atol=1e-12)  # action_rate is a float32 sum upstream
+        dbg = env.debug()
+        for k in ("base_lin_vel", "base_ang_vel", "projected_gravity", "tibia", "feet", "body"):
+            np.testing.assert_allclose(dbg[k], g[k][t], rtol=0, atol=1e-12, err_msg=f"{k} t={t}")
+        qpos, qvel, qw = env.get_state()
+        np.testing.assert_allclose(qpos, g["qpos"][t], atol=1e-13)
+        np.testing.assert_allclose(qvel, g["qvel"][t], atol=1e-12)
+        n, stats = env.episode_stats()
+        assert n == g["nreset"][t]
+        if n:
+            np.testing.assert_allclose(stats, g["ep_stats"][t][order], rtol=1e-6, atol=1e-9)
+
+    replay(oracle_mod, g, check)
+
+
+def test_reference_constants(oracle_mod):
+    g = load_golden("env_reset_rollout.npz")
+    assert list(g["reward_names"]) == ["action_rate", "body_contact_forces", "default_position", "dof_acc", "orientation",
+                                       "termination", "tracking_ang_vel", "tracking_lin_vel"]
+    assert float(g["max_episode_length"]) == 1250.0
+    assert abs(float(g["dt"]) - 0.016) < 1e-15
+    scales = dict(zip(g["reward_names"], g["reward_scales"]))
+    assert abs(scales["termination"] + 3.2) < 1e-12 and abs(scales["tracking_lin_vel"] - 0.128) < 1e-12
+
+
+def test_golden_covers_edge_cases():
+    """The fixtures exercise every branch of E4-E6: timeouts, periodic resample, tilt and force terminations."""
+    g = load_golden("env_timeouts.npz")
+    assert g["time_outs"].sum() >= 3 and (np.abs(np.diff(g["commands"], axis=0)).sum() > 0)
+    f = load_golden("env_falls.npz")
+    assert f["done"].sum() >= 4
+    assert (f["feet"].max(axis=2) > 160).any(), "no hard-landing termination in fixture"
+    pg = f["projected_gravity"]
+    tilt = np.arccos(-pg[..., 2] / np.linalg.norm(pg, axis=-1))
+    assert (tilt > np.pi / 3).any(), "no tilt termination in fixture"
