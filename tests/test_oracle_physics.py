@@ -1,0 +1,204 @@
+"""Known-answer tests that pin the oracle's physics restatement (MuJoCo itself is not available:
+SURVEY.md section 8c lists these as the substitutes for a runnable third-party reference)."""
+import numpy as np
+import pytest
+
+from nightmare_rl_amd.model.compile_model import load_tables, mass_matrix_np, quat_mul, axis_angle_quat
+
+T = load_tables()
+G = 9.81
+
+
+def rand_state(rng, z=0.6, vel=1.0):
+    q = T["qpos0"].copy()
+    q[0:3] = [rng.uniform(-1, 1), rng.uniform(-1, 1), z]
+    quat = rng.normal(size=4)
+    q[3:7] = quat / np.linalg.norm(quat)
+    q[7:] = rng.uniform(-0.6, 0.6, 18)
+    v = rng.normal(size=24) * vel
+    return q, v
+
+
+def test_model_tables():
+    assert abs(T["body_mass"].sum() - 3.0) < 1e-12          # settotalmass=3 (mjmodel.xml:2)
+    assert abs(T["body_mass_exactrule"].sum() - 3.0) < 1e-12
+    # exact-volume cross-check of the mesh integrals (values measured in SURVEY.md P11)
+    np.testing.assert_allclose(T["body_mass_exactrule"][[1, 2, 3, 4]], [1.1875, 0.0742, 0.0289, 0.1990], atol=2e-4)
+    # legs k and k+3 are images of each other under a half-turn about z
+    np.testing.assert_allclose(T["body_mass"][2:11], T["body_mass"][11:20], rtol=2e-3)
+    assert list(T["col_body"]) == [1, 4, 7, 10, 13, 16, 19]
+    assert (T["body_inertia"][1:] > 0).all()
+    for b in range(1, 20):  # triangle inequality of principal inertias
+        i = np.sort(T["body_inertia"][b])
+        assert i[0] + i[1] >= i[2] * (1 - 1e-9)
+
+
+def test_mass_matrix_matches_independent_crba(oracle_mod):
+    rng = np.random.default_rng(0)
+    p = oracle_mod.Physics()
+    for _ in range(5):
+        q, v = rand_state(rng)
+        p.qpos[:] = q
+        p.qvel[:] = v
+        p.forward()
+        M, *_ = mass_matrix_np(T, q)
+        np.testing.assert_allclose(p.qM, M, atol=1e-13)
+        w = np.linalg.eigvalsh(M)
+        assert w.min() > 0
+        # L'DL solve: M qacc_smooth = qfrc_smooth
+        np.testing.assert_allclose(M @ p.qacc_smooth, p.qfrc_smooth, atol=1e-10)
+
+
+def test_free_fall_known_answer(oracle_mod):
+    p = oracle_mod.Physics()
+    h = 0.008
+    for k in range(1, 12):
+        p.step(1)
+        assert abs(p.qpos[2] - (0.15 - G * h * h * k * (k + 1) / 2)) < 1e-13  # semi-implicit Euler
+        assert abs(p.qvel[2] + G * h * k) < 1e-13
+        assert p.ncon == 0
+    np.testing.assert_allclose(p.qpos[7:], 0, atol=1e-12)  # zero ctrl, zero velocity: joints stay put while airborne
+
+
+def test_bias_power_balance(oracle_mod):
+    """qvel . c(q, qvel) = 1/2 qvel' Mdot qvel + d(PE)/dt  (M qacc + c = tau, energy identity)."""
+    rng = np.random.default_rng(1)
+    p = oracle_mod.Physics()
+    eps = 1e-6
+
+    def advance(q, v, dt):
+        q2 = q.copy()
+        q2[0:3] += dt * v[0:3]
+        w = v[3:6]
+        n = np.linalg.norm(w)
+        q2[3:7] = quat_mul(q[3:7], axis_angle_quat(w / n, n * dt))
+        q2[7:] += dt * v[6:]
+        return q2
+
+    def M_and_PE(q):
+        p.qpos[:] = q
+        p.forward()
+        pe = sum(T["body_mass"][b] * G * p.xipos[b][2] for b in range(1, 20))
+        return p.qM.copy(), pe
+
+    for _ in range(4):
+        q, v = rand_state(rng)
+        Mp, PEp = M_and_PE(advance(q, v, eps))
+        Mm, PEm = M_and_PE(advance(q, v, -eps))
+        p.qpos[:] = q
+        p.qvel[:] = v
+        p.forward()
+        lhs = v @ p.qfrc_bias
+        rhs = 0.5 * v @ ((Mp - Mm) / (2 * eps)) @ v + (PEp - PEm) / (2 * eps)
+        assert abs(lhs - rhs) < 1e-6 * max(1.0, abs(lhs))
+
+
+def spatial_momentum(p):
+    """Sum of cinert*cvel about the subtree COM: [angular(3); linear(3)]."""
+    tot = np.zeros(6)
+    for b in range(1, 20):
+        i, v = p.cinert[b], p.cvel[b]
+        I = np.array([[i[0], i[3], i[4]], [i[3], i[1], i[5]], [i[4], i[5], i[2]]])
+        md = i[6:9]
+        tot[:3] += I @ v[:3] + np.cross(md, v[3:])
+        tot[3:] += i[9] * v[3:] - np.cross(md, v[:3])
+    return tot
+
+
+def test_momentum_conservation_in_flight(oracle_mod):
+    rng = np.random.default_rng(2)
+    p = oracle_mod.Physics()
+    q, v = rand_state(rng, z=5.0, vel=0.5)
+    p.qpos[:] = q
+    p.qvel[:] = v
+    p.ctrl[:] = rng.uniform(-3, 3, 18)  # servos are internal forces
+    p.forward()
+    m0 = spatial_momentum(p)
+    com0 = p.subtree_com.copy()
+    n = 25
+    for _ in range(n):
+        p.step(1)
+    p.forward()
+    m1 = spatial_momentum(p)
+    t = n * 0.008
+    assert p.ncon == 0
+    # linear momentum: impulse of gravity, up to the first-order integrator's O(h) drift (M depends on q)
+    np.testing.assert_allclose(m1[3:], m0[3:] + 3.0 * np.array([0, 0, -G]) * t, atol=5e-3)
+    scale = np.abs(T["body_mass"][1] * 0.1 * 0.5) + np.linalg.norm(m0[:3])
+    assert np.linalg.norm(m1[:3] - m0[:3]) < 2e-2 * scale  # angular about the COM: first-order integrator drift only
+    # COM follows the ballistic parabola
+    v_com = m0[3:] / 3.0
+    np.testing.assert_allclose(p.subtree_com, com0 + v_com * t + 0.5 * np.array([0, 0, -G]) * t * (t + 0.008), atol=2e-3)
+
+
+def test_cvel_is_velocity_of_com_point(oracle_mod):
+    """cvel[1] linear part = velocity of the base-fixed point that coincides with the subtree COM (obs uses it: env.py:217)."""
+    rng = np.random.default_rng(3)
+    p = oracle_mod.Physics()
+    q, v = rand_state(rng)
+    p.qpos[:] = q
+    p.qvel[:] = v
+    p.forward()
+    R = p.xmat[1].reshape(3, 3)
+    w = R @ v[3:6]
+    expect = v[0:3] + np.cross(w, p.subtree_com - p.xpos[1])
+    np.testing.assert_allclose(p.cvel[1][3:], expect, atol=1e-13)
+    np.testing.assert_allclose(p.cvel[1][:3], w, atol=1e-13)
+
+
+def test_static_stance_supports_weight(oracle_mod):
+    p = oracle_mod.Physics()
+    for _ in range(600):
+        p.step(1)
+    total = p.sensordata[:6].sum() + p.sensordata[12]  # tibia spheres (r=10 m) + base sphere see every contact once
+    assert abs(total - 3.0 * G) < 0.02 * 3.0 * G
+    assert np.abs(p.qvel).max() < 0.3  # at rest up to slow rocking of the under-iterated (3 PGS sweeps) solve
+    assert p.ncon >= 4
+
+
+def test_constraint_rows_are_consistent(oracle_mod):
+    p = oracle_mod.Physics()
+    rng = np.random.default_rng(4)
+    p.qpos[7:] = np.tile([0.0, -0.7, 0.5], 6) + rng.uniform(-0.1, 0.1, 18)
+    p.qpos[2] = 0.06
+    p.qvel[:] = rng.normal(size=24) * 0.3
+    p.forward()
+    n = p.nefc
+    assert n == 4 * p.ncon and n > 0
+    A = p.efc("AR")
+    np.testing.assert_allclose(A, A.T, atol=1e-12)
+    J = p.s.np("J")[:n]
+    Minv = np.linalg.inv(p.qM)
+    np.testing.assert_allclose(A - np.diag(p.efc("R")), J @ Minv @ J.T, atol=1e-9)
+    f = p.efc_force[:n]
+    assert (f >= 0).all()
+    np.testing.assert_allclose(p.qfrc_constraint, J.T @ f, atol=1e-12)
+    np.testing.assert_allclose(p.qM @ (p.qacc - p.qacc_smooth), p.qfrc_constraint, atol=1e-9)
+    assert (p.con_dist[: p.ncon] < 0).all()
+    # Jacobian rows against finite differences of the contact point height (normal row = (row0+row1)/2)
+    c = 0
+    body = p.con_body[c]
+    Jn = 0.5 * (J[0] + J[1])
+    pos_local = p.xmat[body].reshape(3, 3).T @ (p.con_pos[c] - p.xpos[body])
+    q0 = p.qpos.copy()
+    eps = 1e-7
+    for dof in [2, 4, 6 + (body - 2) if body > 1 else 3]:
+        dv = np.zeros(24)
+        dv[dof] = 1.0
+        q1 = q0.copy()
+        q1[0:3] += eps * dv[0:3]
+        if np.any(dv[3:6]):
+            q1[3:7] = quat_mul(q0[3:7], axis_angle_quat(dv[3:6], eps))
+        q1[7:] += eps * dv[6:]
+        p2 = oracle_mod.Physics()
+        p2.qpos[:] = q1
+        p2.forward()
+        z1 = (p2.xpos[body] + p2.xmat[body].reshape(3, 3) @ pos_local)[2]
+        assert abs((z1 - p.con_pos[c][2]) / eps - Jn[dof]) < 1e-5
+
+
+def test_bad_state_resets_like_mujoco(oracle_mod):
+    p = oracle_mod.Physics()
+    p.qvel[0] = np.nan
+    p.step(1)
+    assert p.nwarning == 1 and np.isfinite(p.qpos).all() and abs(p.qpos[2] - (0.15 - G * 0.008**2)) < 1e-12
