@@ -1,0 +1,108 @@
+/* nightmare_hip.h - C ABI of the MI355X-native NightmareV3Env.step() backend (libnightmare_hip.so).
+ *
+ * Drop-in boundary for the reference's env hot path. Every entry point names the reference interface it
+ * replaces (file:line into the reference tree). Plain pointers and sizes only; device pointers are HIP device
+ * memory on the env's device, `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * All functions return 0 on success, nonzero on error (text via nm_last_error()). There is NO CPU path:
+ * creation fails if no HIP device is usable.
+ */
+#ifndef NIGHTMARE_HIP_H
+#define NIGHTMARE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NM_NUM_OBS 66      /* envs/nightmare_v3_config.py:11 */
+#define NM_NUM_ACTIONS 18  /* envs/nightmare_v3_config.py:13 */
+#define NM_NUM_REWARDS 8   /* non-zero reward scales, envs/nightmare_v3_config.py:78-86 */
+#define NM_DTYPE_F32 0
+#define NM_DTYPE_F64 1     /* verification build of the same kernels in double */
+
+typedef struct nm_env nm_env;
+
+/* The NightmareV3Config fields the step path reads (envs/nightmare_v3_config.py:4-100). Zero-initialised
+ * fields are NOT defaults: start from nm_default_config(). Reward scales are the raw config values (before
+ * the x dt of envs/nightmare_v3_env.py:128), order = nm_reward_name(i). */
+typedef struct {
+  int32_t decimation;               /* control.decimation :45 */
+  double p_gain;                    /* control.p_gain :36 */
+  double action_scale;              /* control.action_scale :46 */
+  double default_pos[3];            /* control.default_pos (coxa, femur, tibia) :39-44 */
+  double clip_actions;              /* normalization.clip_actions :74 */
+  double clip_observations;         /* normalization.clip_observations :73 */
+  double obs_lin_vel, obs_ang_vel, obs_dof_pos, obs_dof_vel; /* normalization.obs_scales :68-71 */
+  double episode_length_s;          /* env.episode_length_s :14 */
+  double resampling_time;           /* commands.resampling_time :60 */
+  double max_lin_vel_x, max_ang_vel;/* commands.ranges :62,:64 */
+  double termination_contact_force; /* env.termination_contact_force :22 */
+  double tracking_sigma;            /* rewards.tracking_sigma :98 */
+  double reward_scales[NM_NUM_REWARDS];
+} nm_config;
+
+void nm_default_config(nm_config* cfg);
+/* "action_rate", "body_contact_forces", "default_position", "dof_acc", "orientation", "tracking_ang_vel",
+ * "tracking_lin_vel", "termination": the order rewards are evaluated in (envs/nightmare_v3_env.py:132-137, 285) */
+const char* nm_reward_name(int i);
+const char* nm_last_error(void);
+
+/* NightmareV3Env.__init__ (envs/nightmare_v3_env.py:27-140): model tables to the device, N env states at qpos0.
+ * env_id_offset = global id of env 0 (multi-GPU sharding: counter-based RNG is keyed by the global id). */
+int nm_create(const nm_config* cfg, int32_t num_envs, int32_t device, uint64_t seed, int64_t env_id_offset,
+              int32_t dtype, nm_env** out);
+int nm_destroy(nm_env* env);
+int32_t nm_num_envs(const nm_env* env);
+int32_t nm_dtype(const nm_env* env);
+
+/* reset_idx(env_ids) (envs/nightmare_v3_env.py:335-371). ids: HOST int32 array, NULL = all envs.
+ * ep_stats_dev [8] f32 receives extras['episode'] (mean episode sums / episode_length_s);
+ * episode_length_dev [N] i64 is the caller-owned episode_length_buf (envs/nightmare_v3_env.py:88). */
+int nm_reset(nm_env* env, const int32_t* ids_host, int32_t n, int64_t* episode_length_dev, float* ep_stats_dev,
+             void* stream);
+
+/* step(actions) (envs/nightmare_v3_env.py:145-311) for all N envs, one launch.
+ *   actions_dev        [N,18] f32 (read only)
+ *   episode_length_dev [N] i64   in/out (episode_length_buf)
+ *   obs_dev [N,66] f32, rew_dev [N] f32, done_dev [N] i64: the returned tuple (:311)
+ *   time_outs_dev [N] f32, ep_stats_dev [8] f32: extras; like the reference (:344-371) they are only
+ *   refreshed by a step in which at least one env reset. */
+int nm_step(nm_env* env, const float* actions_dev, int64_t* episode_length_dev, float* obs_dev, float* rew_dev,
+            int64_t* done_dev, float* time_outs_dev, float* ep_stats_dev, void* stream);
+
+/* Physics only: action -> PD velocity command -> mj_step x decimation (envs/nightmare_v3_env.py:152-210),
+ * no rewards/obs/reset (BASELINE config "dynamics+contact kernel only"). */
+int nm_step_physics(nm_env* env, const float* actions_dev, void* stream);
+
+/* MjData state access (data[i].qpos / qvel / qacc_warmstart, envs/nightmare_v3_env.py:217-221,349-350).
+ * HOST double arrays [N,25] [N,24] [N,24]; NULL entries are skipped. Synchronous. */
+int nm_get_state(nm_env* env, double* qpos, double* qvel, double* qacc_warmstart);
+int nm_set_state(nm_env* env, const double* qpos, const double* qvel, const double* qacc_warmstart);
+/* The host-side buffers the reference keeps between steps (self.dof_pos, self.dof_vel, self.actions,
+ * self.commands, self.episode_sums; envs/nightmare_v3_env.py:60-61,94-96,140). HOST doubles, NULL = skip.
+ * episode_sums is [N,8] in nm_reward_name order. */
+int nm_get_buffers(nm_env* env, double* dof_pos, double* dof_vel, double* actions, double* commands, double* episode_sums);
+int nm_set_buffers(nm_env* env, const double* dof_pos, const double* dof_vel, const double* actions,
+                   const double* commands, const double* episode_sums);
+/* RNG-free command resampling for parity tests: HOST [N,4] uniforms in [0,1) used by the next steps instead
+ * of the counter RNG ((x,yaw) for the periodic resample :235, (x,yaw) for the reset resample :356). NULL = RNG. */
+int nm_set_command_uniforms(nm_env* env, const double* u_host);
+/* counters: [0] contacts dropped by the per-env contact cap, [1] MuJoCo-style bad-state resets */
+int nm_get_counters(nm_env* env, int64_t* out2);
+/* optional debug dump [N,256] reals (dtype of the env) written by nm_step; NULL disables */
+int nm_set_debug_buffer(nm_env* env, void* dbg_dev);
+
+/* Measurement hook (no reference counterpart): when enabled, every nm_step / nm_step_physics brackets its step
+ * kernel with HIP events on the launch stream. Each call synchronises, returns the summed kernel time and the
+ * launch count since the previous call, clears them, and sets the new enable state. */
+int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count);
+
+/* ActorCritic.act mean path (rsl_rl v1.0.2 ActorCritic: Linear->ELU x n_hidden -> Linear), batched over envs
+ * on the MFMA units. weights: device f32, layer l is [out_l, in_l] row-major followed by bias [out_l]
+ * (torch.nn.Linear layout); dims = {66, h1, ..., 18}, n_layers = len(dims)-1. */
+int nm_policy_forward(const float* obs_dev, int32_t num_envs, const float* const* weights_dev, const float* const* bias_dev,
+                      const int32_t* dims, int32_t n_layers, float* actions_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,73 @@
+"""ctypes binding of libnightmare_hip.so (C ABI: include/nightmare_hip.h). No fallback: if the HIP library is
+missing or no GPU is usable, this raises."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "csrc", "libnightmare_hip.so")
+NUM_OBS, NUM_ACTIONS, NUM_REWARDS = 66, 18, 8
+DTYPE_F32, DTYPE_F64 = 0, 1
+
+EXPORTS = ["nm_default_config", "nm_reward_name", "nm_last_error", "nm_create", "nm_destroy", "nm_num_envs", "nm_dtype", "nm_reset",
+           "nm_step", "nm_step_physics", "nm_get_state", "nm_set_state", "nm_get_buffers", "nm_set_buffers",
+           "nm_set_command_uniforms", "nm_get_counters", "nm_set_debug_buffer", "nm_policy_forward", "nm_profile"]
+
+
+class NmConfig(C.Structure):
+    _fields_ = [("decimation", C.c_int32), ("p_gain", C.c_double), ("action_scale", C.c_double), ("default_pos", C.c_double * 3),
+                ("clip_actions", C.c_double), ("clip_observations", C.c_double),
+                ("obs_lin_vel", C.c_double), ("obs_ang_vel", C.c_double), ("obs_dof_pos", C.c_double), ("obs_dof_vel", C.c_double),
+                ("episode_length_s", C.c_double), ("resampling_time", C.c_double), ("max_lin_vel_x", C.c_double), ("max_ang_vel", C.c_double),
+                ("termination_contact_force", C.c_double), ("tracking_sigma", C.c_double), ("reward_scales", C.c_double * NUM_REWARDS)]
+
+
+class NightmareHipError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP extension. Raises if it has not been built (python __graft_entry__.py / make -C nightmare_rl_amd/csrc)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NightmareHipError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
+                                "There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.nm_default_config.argtypes = [C.POINTER(NmConfig)]
+    L.nm_default_config.restype = None
+    L.nm_reward_name.argtypes = [C.c_int]
+    L.nm_reward_name.restype = C.c_char_p
+    L.nm_last_error.restype = C.c_char_p
+    L.nm_create.argtypes = [C.POINTER(NmConfig), C.c_int32, C.c_int32, C.c_uint64, C.c_int64, C.c_int32, C.POINTER(vp)]
+    L.nm_destroy.argtypes = [vp]
+    L.nm_num_envs.argtypes = [vp]
+    L.nm_dtype.argtypes = [vp]
+    L.nm_reset.argtypes = [vp, vp, C.c_int32, vp, vp, vp]
+    L.nm_step.argtypes = [vp] * 9
+    L.nm_step_physics.argtypes = [vp, vp, vp]
+    L.nm_get_state.argtypes = [vp] * 4
+    L.nm_set_state.argtypes = [vp] * 4
+    L.nm_get_buffers.argtypes = [vp] * 6
+    L.nm_set_buffers.argtypes = [vp] * 6
+    L.nm_set_command_uniforms.argtypes = [vp, vp]
+    L.nm_get_counters.argtypes = [vp, vp]
+    L.nm_set_debug_buffer.argtypes = [vp, vp]
+    L.nm_profile.argtypes = [vp, C.c_int32, vp, vp]
+    L.nm_policy_forward.argtypes = [vp, C.c_int32, vp, vp, vp, C.c_int32, vp, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise NightmareHipError(load().nm_last_error().decode())
+
+
+def reward_names():
+    L = load()
+    return [L.nm_reward_name(i).decode() for i in range(NUM_REWARDS)]

@@ -1,0 +1,1172 @@
+// nm_core.h - NightmareV3Env.step() for ONE env on ONE 64-lane wavefront (CDNA4), written against simt.h.
+//
+// Path restated (reference file:line): envs/nightmare_v3_env.py:145-311 (step), :321-371 (command resample,
+// reset_idx) and, below it, what MuJoCo 3.1.2's mj_step executes for models/nightmare_v3/mjmodel.xml
+// (SURVEY.md section 8a rows E1-E8, P1-P10).  Algorithmically equivalent to oracle/ but laid out for the
+// hardware instead of following MuJoCo's data structures:
+//
+//   stage A  "lane = leg"  (6 lanes + redundant uniform base math): kinematics, spatial inertias about the
+//            BASE ORIGIN (world axes), composite inertias, joint-space inertia as blocks
+//            [Mbb 6x6 | Mlb_l 3x6 | M_l 3x3] (legs only couple through the base), block factorisation
+//            (L'DL of M_l, W_l = M_l^-1 Mlb_l, Schur complement LDL'), RNE bias, servo forces, qacc_smooth.
+//            Done for M and for M + h*kv*I (implicitfast) in one pass.
+//   stage B  "lane = hull vertex": plane-vs-convex-hull support search for the 7 colliding meshes
+//            (wave arg-max), up to 3 extra penetrating hull neighbours chosen by ballot.
+//   stage C  "lane = constraint row" (4 pyramid rows per contact, <= 64 rows): sparse Jacobian row (6 base +
+//            3 own-leg entries), B_i = M^-1 J_i' by the block factor, A = J M^-1 J' held as one ROW PER LANE IN
+//            REGISTERS, warm start, PGS x3 and NoSlip x4 as statically unrolled sweeps that broadcast the
+//            updated row's delta with v_readlane and rank-1 update every lane's residual.
+//   stage D  "lane = leg": implicitfast solve, semi-implicit Euler, quaternion integration.
+//   epilogue "lane = observation slot": frame transforms, termination, reset, rewards, obs.
+//
+// All inter-stage traffic goes through ~6.6 KB of LDS per wave; HBM is touched once per env-step
+// (state in, state + obs out).
+#pragma once
+#include "simt.h"
+
+namespace nm {
+using namespace simt;
+
+// ----------------------------------------------------------------------------------------- layout constants
+constexpr int kNQ = 25, kNV = 24, kNU = 18, kNLEG = 6, kNCOL = 7, kNSENS = 13, kNOBS = 66, kNREW = 8;
+constexpr int kLinkN = 25;             // per-link constants: bpos3 bR9 axis3 ipos3 Ibody6 mass1
+constexpr int kLegN = 3 * kLinkN;      // per-leg constants
+constexpr int kBaseN = 10;             // ipos3 Ibody6 mass1
+constexpr int kColN = 8;               // per colliding mesh: center3 rbound invweight0 nvert vadr pad
+constexpr int kMaxCon = 16;            // contacts kept per env (rows = 4*kMaxCon = one per lane)
+constexpr int kMaxRow = 4 * kMaxCon;
+constexpr int kJRow = 12;              // LDS row: Jb6 Jl3 leg pad2
+enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
+
+// model + config constants, converted once to `real` by the host and kept in HBM/L2 (shared by all envs)
+template <class real> struct Model {
+  const real* legc;     // [6][kLegN]
+  const real* basec;    // [kBaseN]
+  const real* colc;     // [7][kColN]
+  const real* hullv;    // [nhull][4] xyz0, body frame
+  const int* hullnbr;   // [nhull][maxnbr] local vertex ids, -1 terminated
+  const real* footc;    // [6][4] foot site pos (tibia frame) + radius
+  const real* qpos0;    // [kNQ]
+  int maxnbr;
+  real total_mass;
+  real h, kv, ctrl_max, grav, mu;
+  real solref_K, solref_B, si_d0, si_dmax, si_width, si_mid, si_power;
+  real pgs_scale, pgs_tol, noslip_tol, tol_planemesh;
+  int pgs_iters, noslip_iters;
+  // env config (reference envs/nightmare_v3_config.py)
+  real dt, p_gain, clip_obs, obs_lin, obs_ang, obs_dofpos, obs_dofvel, max_lin_x, max_ang, term_force, sigma, max_ep_len, default_pos[3];
+  float action_scale, clip_actions;
+  int resample_every;
+  real rew_scale[kNREW];
+  real ep_len_s;
+};
+
+// per-launch arguments (device pointers, AoS-by-env rows so one wave reads contiguous bytes)
+template <class real> struct Args {
+  int N;
+  uint64_t seed;
+  int64_t env_offset;
+  // physics state
+  real *qpos, *qvel, *qwarm;
+  // env buffers the reference keeps between steps
+  real *dofpos, *dofvel, *act, *cmd, *epsum;
+  int64_t* eplen;
+  uint32_t* rngctr;
+  // inputs
+  const float* actions;  // [N,18]
+  const real* cmd_u;     // [N,4] or null
+  // outputs
+  float *obs, *rew, *timeout_now;
+  int64_t* done;
+  real* stat_sum;        // [kNREW] sums of episode sums over envs that reset this step
+  int* stat_cnt;         // [4]: #resets this step, #contacts dropped (contact cap), #bad-state resets (mj_check*)
+  real* dbg;             // optional [N][kDbgN]
+  int nsub;              // decimation
+  int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
+};
+constexpr int kDbgN = 256;
+
+// ----------------------------------------------------------------------------------------- LDS image of one env
+template <class real> struct Sh {
+  real qpos[28], qvel[24], warm[24], ctrl[20];
+  real Rb[9], wv[6];             // base rotation; base spatial velocity [w_world; v_origin]
+  real anc[kNU * 3], axs[kNU * 3];  // hinge anchors (relative to base origin) and axes, world-aligned
+  real colR[kNCOL * 9], colp[kNCOL * 3];
+  real Minv[kNLEG * 6], W[kNLEG * 18], Lb[15], Dbi[6];      // factor of M
+  real MinvH[kNLEG * 6], WH[kNLEG * 18], LbH[15], DbiH[6];  // factor of M + h kv I
+  real qas[24], qfs[24], qfc[24];
+  real cpos[kMaxCon * 3], cdist[kMaxCon];
+  int cleg[kMaxCon];
+  real jrow[kMaxRow * kJRow];
+  real sens[16], cvb[6];
+  real efc_f[kMaxRow];
+#ifdef NM_DEBUG_SOLVER
+  real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
+#endif
+  int ncon, nwarn, it_pgs, it_noslip;
+};
+
+// ----------------------------------------------------------------------------------------- small algebra
+template <class A, class B, class C> NM_FN void cross3(A* r, const B* a, const C* b) {
+  A x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <class A, class B, class C> NM_FN A dot3(const B* a, const C* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class A, class B, class C> NM_FN void matvec3(A* r, const B* m, const C* v) {
+  A x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+template <class A, class B, class C> NM_FN void matmul3(A* r, const B* a, const C* b) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) r[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+// spatial inertia (Ixx Iyy Izz Ixy Ixz Iyz, m*d(3), m) times motion vector [ang; lin]
+template <class A, class B, class C> NM_FN void inert_mul(A* r, const B* i, const C* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+template <class A, class B, class C> NM_FN void cross_motion(A* r, const B* vel, const C* v) {
+  A a[3], b[3], c[3];
+  cross3(a, vel, v); cross3(b, vel, v + 3); cross3(c, vel + 3, v);
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = b[0] + c[0]; r[4] = b[1] + c[1]; r[5] = b[2] + c[2];
+}
+template <class A, class B, class C> NM_FN void cross_force(A* r, const B* vel, const C* f) {
+  A a[3], b[3], c[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3); cross3(c, vel, f + 3);
+  r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; r[3] = c[0]; r[4] = c[1]; r[5] = c[2];
+}
+template <class A, class B, class C> NM_FN A dot6(const B* a, const C* b) {
+  return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3] + a[4] * b[4] + a[5] * b[5];
+}
+// sum over the six leg lanes (lanes 0..5) -> wave-uniform
+template <class real> NM_FN real lanesum6(const V<real>& x) {
+  return ((rdlane(x, 0) + rdlane(x, 1)) + (rdlane(x, 2) + rdlane(x, 3))) + (rdlane(x, 4) + rdlane(x, 5));
+}
+// spatial inertia of a body about the reference point: body-frame tensor Ib(6), rotation R, COM offset d, mass m
+template <class X, class real> NM_FN void spatial_inertia(X* I10, const X* R, const X* Ib, const X* d, X m, real) {
+  X T[9];  // R * Ib
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    T[3 * i + 0] = R[3 * i] * Ib[0] + R[3 * i + 1] * Ib[3] + R[3 * i + 2] * Ib[4];
+    T[3 * i + 1] = R[3 * i] * Ib[3] + R[3 * i + 1] * Ib[1] + R[3 * i + 2] * Ib[5];
+    T[3 * i + 2] = R[3 * i] * Ib[4] + R[3 * i + 1] * Ib[5] + R[3 * i + 2] * Ib[2];
+  }
+  X xx = T[0] * R[0] + T[1] * R[1] + T[2] * R[2], yy = T[3] * R[3] + T[4] * R[4] + T[5] * R[5], zz = T[6] * R[6] + T[7] * R[7] + T[8] * R[8];
+  X xy = T[0] * R[3] + T[1] * R[4] + T[2] * R[5], xz = T[0] * R[6] + T[1] * R[7] + T[2] * R[8], yz = T[3] * R[6] + T[4] * R[7] + T[5] * R[8];
+  I10[0] = xx + m * (d[1] * d[1] + d[2] * d[2]);
+  I10[1] = yy + m * (d[0] * d[0] + d[2] * d[2]);
+  I10[2] = zz + m * (d[0] * d[0] + d[1] * d[1]);
+  I10[3] = xy - m * d[0] * d[1];
+  I10[4] = xz - m * d[0] * d[2];
+  I10[5] = yz - m * d[1] * d[2];
+  I10[6] = m * d[0]; I10[7] = m * d[1]; I10[8] = m * d[2];
+  I10[9] = m;
+}
+// L'DL of a symmetric 3x3 leg block (entries 00 01 02 11 12 22; 0 = coxa ... 2 = tibia), eliminating the
+// leaf (tibia) first as mj_factorM does: backward stable on these graded blocks (the cofactor inverse is not
+// and costs fp32 three digits). Factor = (l21 l20 l10 1/d2 1/d1 1/d0).
+template <class X, class real> NM_FN void ldl3(X* r, const X* a, real one) {
+  X i2 = X(one) / a[5];
+  X l21 = a[4] * i2, l20 = a[2] * i2;
+  X m11 = a[3] - l21 * a[4], m01 = a[1] - l21 * a[2], m00 = a[0] - l20 * a[2];
+  X i1 = X(one) / m11;
+  X l10 = m01 * i1;
+  X d0 = m00 - l10 * m01;
+  r[0] = l21; r[1] = l20; r[2] = l10; r[3] = i2; r[4] = i1; r[5] = X(one) / d0;
+}
+template <class X, class Y> NM_FN void ldl3_solve(X* x, const X* f, const Y* y) {
+  X y2 = y[2];
+  X y1 = y[1] - f[0] * y2;
+  X y0 = y[0] - f[1] * y2 - f[2] * y1;
+  X x0 = y0 * f[5];
+  X x1 = y1 * f[4] - f[2] * x0;
+  x[2] = y2 * f[3] - f[0] * x1 - f[1] * x0;
+  x[1] = x1; x[0] = x0;
+}
+// LDL' of a symmetric 6x6 given as full row-major S[36] (uniform): L strictly lower (15, row-major packed), Dinv(6)
+template <class real> NM_FN void ldl6(const real* S, real* L, real* Dinv) {
+  real Lf[36], D[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    real d = S[7 * j];
+#pragma unroll
+    for (int k = 0; k < j; k++) d = d - Lf[6 * j + k] * Lf[6 * j + k] * D[k];
+    D[j] = d;
+    real di = real(1) / d;
+    Dinv[j] = di;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      real s = S[6 * i + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) s = s - Lf[6 * i + k] * Lf[6 * j + k] * D[k];
+      Lf[6 * i + j] = s * di;
+    }
+  }
+  int n = 0;
+#pragma unroll
+  for (int i = 1; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) L[n++] = Lf[6 * i + j];
+}
+// x <- (L D L')^-1 x ; L, Dinv wave-uniform (LDS), x per lane or uniform
+template <class X, class real> NM_FN void ldl6_solve(const real* L, const real* Dinv, X* x) {
+  int n = 0;
+#pragma unroll
+  for (int i = 1; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j < i; j++) x[i] = x[i] - L[n++] * x[j];
+#pragma unroll
+  for (int i = 0; i < 6; i++) x[i] = x[i] * Dinv[i];
+#pragma unroll
+  for (int i = 5; i >= 1; i--) {
+    n = i * (i - 1) / 2;
+#pragma unroll
+    for (int j = 0; j < i; j++) x[j] = x[j] - L[n + j] * x[i];
+  }
+}
+
+// counter-based uniform in [0,1) with 24 random bits (same definition as oracle/nm_oracle_env.c nmo_rand_u24)
+NM_FN uint32_t rand_u24_bits(uint64_t seed, uint64_t genv, uint32_t ctr) {
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (genv + 1) + 0xD1B54A32D192ED03ull * (uint64_t)ctr;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 40);
+}
+
+// =========================================================================================  stage A
+// Everything "smooth": kinematics, inertia blocks + both factorisations, bias, servo forces, qacc_smooth.
+template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M, bool last) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const V<int> leg = lane % 6;
+  const VB isleg = lane < 6;
+
+  // ---- base frame (uniform)
+  real qw = sh.qpos[3], qx = sh.qpos[4], qy = sh.qpos[5], qz = sh.qpos[6];
+  real Rb[9];
+  {
+    real q00 = qw * qw, q01 = qw * qx, q02 = qw * qy, q03 = qw * qz, q11 = qx * qx, q12 = qx * qy, q13 = qx * qz, q22 = qy * qy,
+         q23 = qy * qz, q33 = qz * qz;
+    Rb[0] = q00 + q11 - q22 - q33; Rb[4] = q00 - q11 + q22 - q33; Rb[8] = q00 - q11 - q22 + q33;
+    Rb[1] = real(2) * (q12 - q03); Rb[2] = real(2) * (q13 + q02); Rb[3] = real(2) * (q12 + q03);
+    Rb[5] = real(2) * (q23 - q01); Rb[6] = real(2) * (q13 - q02); Rb[7] = real(2) * (q23 + q01);
+  }
+  real vb[6];  // base spatial velocity about its origin: [w_world; v_origin]
+  {
+    real wl[3] = {sh.qvel[3], sh.qvel[4], sh.qvel[5]};
+    matvec3(vb, Rb, wl);
+    vb[3] = sh.qvel[0]; vb[4] = sh.qvel[1]; vb[5] = sh.qvel[2];
+  }
+  real ab[6];  // base bias acceleration: -gravity + v x w  (cdof_dot of the free joint's rotational dofs)
+  {
+    real t[3];
+    cross3(t, vb + 3, vb);
+    ab[0] = ab[1] = ab[2] = real(0);
+    ab[3] = t[0]; ab[4] = t[1]; ab[5] = t[2] + M.grav;
+  }
+  // base body spatial inertia about its own origin
+  real Ib10[10], bcom[3];
+  {
+    real ipos[3] = {M.basec[0], M.basec[1], M.basec[2]}, Ibody[6] = {M.basec[3], M.basec[4], M.basec[5], M.basec[6], M.basec[7], M.basec[8]};
+    real d[3];
+    matvec3(d, Rb, ipos);
+    spatial_inertia(Ib10, Rb, Ibody, d, M.basec[9], real(0));
+    bcom[0] = M.basec[9] * d[0]; bcom[1] = M.basec[9] * d[1]; bcom[2] = M.basec[9] * d[2];  // mass-weighted, legs added below
+  }
+
+  // ---- leg chains, one leg per lane
+  vr Rp[9], pp[3];
+#pragma unroll
+  for (int k = 0; k < 9; k++) Rp[k] = vr(Rb[k]);
+  pp[0] = pp[1] = pp[2] = vr(real(0));
+  vr S[3][6], I10[3][10], vk[3][6], fk[3][6];
+  vr vpar[6], apar[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { vpar[k] = vr(vb[k]); apar[k] = vr(ab[k]); }
+  vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const V<int> cb = leg * kLegN + k * kLinkN;
+    vr c[kLinkN];
+#pragma unroll
+    for (int j = 0; j < kLinkN; j++) c[j] = gldv(M.legc, cb + j);
+    vr q = ldsv(sh.qpos, leg * 3 + (7 + k)), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
+    vr pos[3], t3[3], R0[9], aw[3];
+    matvec3(t3, Rp, c + 0);
+    pos[0] = pp[0] + t3[0]; pos[1] = pp[1] + t3[1]; pos[2] = pp[2] + t3[2];
+    matmul3(R0, Rp, c + 3);
+    matvec3(aw, R0, c + 12);
+    vr s, co;
+    vsincos(q, &s, &co);
+    vr Rl[9];  // Rodrigues about the local axis
+    {
+      const vr* a = c + 12;
+      vr oc = vr(real(1)) - co;
+      Rl[0] = co + oc * a[0] * a[0]; Rl[1] = oc * a[0] * a[1] - s * a[2]; Rl[2] = oc * a[0] * a[2] + s * a[1];
+      Rl[3] = oc * a[0] * a[1] + s * a[2]; Rl[4] = co + oc * a[1] * a[1]; Rl[5] = oc * a[1] * a[2] - s * a[0];
+      Rl[6] = oc * a[0] * a[2] - s * a[1]; Rl[7] = oc * a[1] * a[2] + s * a[0]; Rl[8] = co + oc * a[2] * a[2];
+    }
+    vr R[9];
+    matmul3(R, R0, Rl);
+    vr d[3];
+    matvec3(t3, R, c + 15);
+    d[0] = pos[0] + t3[0]; d[1] = pos[1] + t3[1]; d[2] = pos[2] + t3[2];
+    spatial_inertia(I10[k], R, c + 18, d, c[24], real(0));
+    mcom[0] += c[24] * d[0]; mcom[1] += c[24] * d[1]; mcom[2] += c[24] * d[2];
+    // motion vector about the base origin: [a; r x a]
+    S[k][0] = aw[0]; S[k][1] = aw[1]; S[k][2] = aw[2];
+    cross3(S[k] + 3, pos, aw);
+    // publish joint anchor/axis (row stage) and, for the tibia, the collision frame
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      stsv(sh.anc, leg * 9 + (3 * k + j), pos[j], isleg);
+      stsv(sh.axs, leg * 9 + (3 * k + j), aw[j], isleg);
+    }
+    if (k == 2) {
+#pragma unroll
+      for (int j = 0; j < 9; j++) stsv(sh.colR, (leg + 1) * 9 + j, R[j], isleg);
+#pragma unroll
+      for (int j = 0; j < 3; j++) stsv(sh.colp, (leg + 1) * 3 + j, pos[j], isleg);
+    }
+    // RNE forward: velocity, bias acceleration, body force
+    vr Sd[6], a[6], t6[6], u6[6];
+    cross_motion(Sd, vpar, S[k]);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      vk[k][j] = vpar[j] + S[k][j] * qd;
+      a[j] = apar[j] + Sd[j] * qd;
+    }
+    inert_mul(t6, I10[k], a);
+    inert_mul(u6, I10[k], vk[k]);
+    cross_force(fk[k], vk[k], u6);
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      fk[k][j] = fk[k][j] + t6[j];
+      vpar[j] = vk[k][j];
+      apar[j] = a[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 9; j++) Rp[j] = R[j];
+    pp[0] = pos[0]; pp[1] = pos[1]; pp[2] = pos[2];
+  }
+  // base collision frame + base rotation for the row stage
+#pragma unroll
+  for (int j = 0; j < 9; j++) { sh.colR[j] = Rb[j]; sh.Rb[j] = Rb[j]; }
+  sh.colp[0] = sh.colp[1] = sh.colp[2] = real(0);
+#pragma unroll
+  for (int j = 0; j < 6; j++) sh.wv[j] = vb[j];
+  if (last) {  // subtree COM (relative to the base origin) -> cvel[1] as MuJoCo reports it (about the COM)
+    real cr[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) cr[j] = (bcom[j] + lanesum6<real>(mcom[j])) / M.total_mass;
+    real t[3];
+    cross3(t, vb, cr);
+    sh.cvb[0] = vb[0]; sh.cvb[1] = vb[1]; sh.cvb[2] = vb[2];
+    sh.cvb[3] = vb[3] + t[0]; sh.cvb[4] = vb[4] + t[1]; sh.cvb[5] = vb[5] + t[2];
+  }
+
+  // ---- RNE backward + generalized bias
+#pragma unroll
+  for (int j = 0; j < 6; j++) { fk[1][j] += fk[2][j]; }
+#pragma unroll
+  for (int j = 0; j < 6; j++) { fk[0][j] += fk[1][j]; }
+  vr cl[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) cl[k] = dot6<vr>(S[k], fk[k]);
+  real fb[6];
+  {
+    real t6[6], u6[6], w6[6];
+    inert_mul(t6, Ib10, ab);
+    inert_mul(u6, Ib10, vb);
+    cross_force(w6, vb, u6);
+#pragma unroll
+    for (int j = 0; j < 6; j++) fb[j] = t6[j] + w6[j] + lanesum6<real>(fk[0][j]);
+  }
+  real cbias[6];
+  cbias[0] = fb[3]; cbias[1] = fb[4]; cbias[2] = fb[5];
+#pragma unroll
+  for (int j = 0; j < 3; j++) cbias[3 + j] = Rb[j] * fb[0] + Rb[3 + j] * fb[1] + Rb[6 + j] * fb[2];
+
+  // ---- composite inertias and the inertia blocks
+#pragma unroll
+  for (int j = 0; j < 10; j++) { I10[1][j] += I10[2][j]; }
+#pragma unroll
+  for (int j = 0; j < 10; j++) { I10[0][j] += I10[1][j]; }
+  real Icb[10];
+#pragma unroll
+  for (int j = 0; j < 10; j++) Icb[j] = Ib10[j] + lanesum6<real>(I10[0][j]);
+  vr F[3][6];
+#pragma unroll
+  for (int k = 0; k < 3; k++) inert_mul(F[k], I10[k], S[k]);
+  vr Ml[6];  // 00 01 02 11 12 22 (0 = coxa)
+  Ml[0] = dot6<vr>(S[0], F[0]); Ml[1] = dot6<vr>(S[0], F[1]); Ml[2] = dot6<vr>(S[0], F[2]);
+  Ml[3] = dot6<vr>(S[1], F[1]); Ml[4] = dot6<vr>(S[1], F[2]); Ml[5] = dot6<vr>(S[2], F[2]);
+  vr Mlb[3][6];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    Mlb[k][0] = F[k][3]; Mlb[k][1] = F[k][4]; Mlb[k][2] = F[k][5];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Mlb[k][3 + j] = F[k][0] * Rb[j] + F[k][1] * Rb[3 + j] + F[k][2] * Rb[6 + j];
+  }
+  real Mbb[36];
+  {
+    real Sb[6][6], Fb[6][6];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) { Sb[j][k] = real(0); Sb[3 + j][k] = real(0); }
+      Sb[j][3 + j] = real(1);
+      Sb[3 + j][0] = Rb[j]; Sb[3 + j][1] = Rb[3 + j]; Sb[3 + j][2] = Rb[6 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) inert_mul(Fb[j], Icb, Sb[j]);
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) Mbb[6 * i + j] = dot6<real>(Sb[i], Fb[j]);
+  }
+
+  // ---- block factorisations: M (pass 0) and M + h*kv*I on the actuated dofs (pass 1, implicitfast)
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    vr Mh[6];
+    real dg = pass ? M.h * M.kv : real(0);
+    Mh[0] = Ml[0] + dg; Mh[1] = Ml[1]; Mh[2] = Ml[2]; Mh[3] = Ml[3] + dg; Mh[4] = Ml[4]; Mh[5] = Ml[5] + dg;
+    vr Mi[6], W[3][6];
+    ldl3(Mi, Mh, real(1));
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      vr col[3] = {Mlb[0][j], Mlb[1][j], Mlb[2][j]}, r3[3];
+      ldl3_solve(r3, Mi, col);
+      W[0][j] = r3[0]; W[1][j] = r3[1]; W[2][j] = r3[2];
+    }
+    real Sc[36];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++) {
+        vr cij = Mlb[0][i] * W[0][j] + Mlb[1][i] * W[1][j] + Mlb[2][i] * W[2][j];
+        real s = Mbb[6 * i + j] - lanesum6<real>(cij);
+        Sc[6 * i + j] = s; Sc[6 * j + i] = s;
+      }
+    real L[15], Di[6];
+    ldl6(Sc, L, Di);
+    real* shMinv = pass ? sh.MinvH : sh.Minv;
+    real* shW = pass ? sh.WH : sh.W;
+    real* shL = pass ? sh.LbH : sh.Lb;
+    real* shD = pass ? sh.DbiH : sh.Dbi;
+#pragma unroll
+    for (int j = 0; j < 6; j++) stsv(shMinv, leg * 6 + j, Mi[j], isleg);
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int j = 0; j < 6; j++) stsv(shW, leg * 18 + (6 * k + j), W[k][j], isleg);
+#pragma unroll
+    for (int j = 0; j < 15; j++) shL[j] = L[j];
+#pragma unroll
+    for (int j = 0; j < 6; j++) shD[j] = Di[j];
+    if (pass == 0) {
+      // ---- servo forces, qfrc_smooth, qacc_smooth = M^-1 qfrc_smooth (block solve in the leg layout)
+      vr y[3], t[3];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        vr ctrl = ldsv(sh.ctrl, leg * 3 + k), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
+        ctrl = vmin(vmax(ctrl, vr(-M.ctrl_max)), vr(M.ctrl_max));
+        y[k] = M.kv * ctrl - M.kv * qd - cl[k];
+        stsv(sh.qfs, leg * 3 + (6 + k), y[k], isleg);
+      }
+      ldl3_solve(t, Mi, y);
+      real xb[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) {
+        vr wy = W[0][j] * y[0] + W[1][j] * y[1] + W[2][j] * y[2];
+        xb[j] = -cbias[j] - lanesum6<real>(wy);
+        sh.qfs[j] = -cbias[j];
+      }
+      ldl6_solve(L, Di, xb);
+#pragma unroll
+      for (int j = 0; j < 6; j++) sh.qas[j] = xb[j];
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        vr x = t[k];
+#pragma unroll
+        for (int j = 0; j < 6; j++) x = x - W[k][j] * xb[j];
+        stsv(sh.qas, leg * 3 + (6 + k), x, isleg);
+      }
+    }
+  }
+  wave_sync();
+}
+
+// =========================================================================================  stage B
+// Floor (z = 0) against the convex hulls of base_link and the six tibias.
+template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  int ncon = 0;
+  const real bz = sh.qpos[2];
+  for (int g = 0; g < kNCOL; g++) {
+    const real* R = sh.colR + 9 * g;
+    const real* p = sh.colp + 3 * g;
+    const real* cc = M.colc + kColN * g;
+    const real pz = p[2] + bz;
+    // bounding-sphere prefilter
+    real cz = R[6] * cc[0] + R[7] * cc[1] + R[8] * cc[2] + pz;
+    if (cz - cc[3] > real(0)) continue;
+    const int nvert = (int)cc[5], vadr = (int)cc[6];
+    const real ld[3] = {-R[6], -R[7], -R[8]};  // -normal in the mesh frame
+    vr best = vr(real(-1e30));
+    V<int> ibest = lane;
+    for (int it = 0; it * NM_WAVE < nvert; it++) {
+      V<int> vi = lane + it * NM_WAVE;
+      VB ok = vi < nvert;
+      V<int> ad = (sel(ok, vi, V<int>(0)) + vadr) * 4;
+      vr val = ld[0] * gldv(M.hullv, ad) + ld[1] * gldv(M.hullv, ad + 1) + ld[2] * gldv(M.hullv, ad + 2);
+      VB take = ok & (val > best);
+      best = sel(take, val, best);
+      ibest = sel(take, vi, ibest);
+    }
+    real sv; int si;
+    wargmax(best, ibest, &sv, &si);
+    const real dist = pz - sv;
+    if (dist >= real(0)) continue;
+    if (ncon >= kMaxCon) { *dropped += 1; continue; }
+    const real* v0 = M.hullv + 4 * (vadr + si);
+    real first[3];
+    {
+      real t[3];
+      matvec3(t, R, v0);
+      first[0] = p[0] + t[0]; first[1] = p[1] + t[1]; first[2] = p[2] + t[2] - real(0.5) * dist;
+    }
+    sh.cpos[3 * ncon] = first[0]; sh.cpos[3 * ncon + 1] = first[1]; sh.cpos[3 * ncon + 2] = first[2];
+    sh.cdist[ncon] = dist;
+    sh.cleg[ncon] = g - 1;
+    ncon++;
+    // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
+    const real tol = M.tol_planemesh * cc[3];
+    VB valid = lane < M.maxnbr;
+    V<int> nb = gldv(M.hullnbr, sel(valid, lane, V<int>(0)) + (vadr + si) * M.maxnbr);
+    valid = valid & (nb >= 0);
+    V<int> ad = (sel(valid, nb, V<int>(0)) + vadr) * 4;
+    vr v[3] = {gldv(M.hullv, ad), gldv(M.hullv, ad + 1), gldv(M.hullv, ad + 2)};
+    vr val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
+    vr pnt[3];
+    matvec3(pnt, R, v);
+    pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
+    vr dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
+    vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+    VB ok = valid & (val > vr(pz)) & !(vsqrt(d2) < vr(tol));
+    uint64_t m = ballot(ok);
+    for (int extra = 0; extra < 3 && m; extra++) {
+      int e = __builtin_ctzll(m);
+      m &= m - 1;
+      if (ncon >= kMaxCon) { *dropped += 1; continue; }
+      VB me = lane == e;
+      vr cd = pnt[2] + bz;
+      stsv(sh.cpos, V<int>(3 * ncon), pnt[0], me);
+      stsv(sh.cpos, V<int>(3 * ncon + 1), pnt[1], me);
+      stsv(sh.cpos, V<int>(3 * ncon + 2), pnt[2] - real(0.5) * cd, me);
+      stsv(sh.cdist, V<int>(ncon), cd, me);
+      sh.cleg[ncon] = g - 1;
+      ncon++;
+    }
+  }
+  sh.ncon = ncon;
+  wave_sync();
+}
+
+// =========================================================================================  stage C
+// Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
+template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const int ncon = uniform(sh.ncon), nefc = 4 * ncon;
+  if (nefc == 0) {
+#pragma unroll
+    for (int j = 0; j < 24; j++) sh.qfc[j] = real(0);
+    if (last)
+#pragma unroll
+      for (int j = 0; j < kNSENS; j++) sh.sens[j] = real(0);
+    wave_sync();
+    return;
+  }
+  const VB act = lane < nefc;
+  const V<int> c = sel(act, lane >> 2, V<int>(0));
+  const V<int> tk = (lane >> 1) & 1, sg = lane & 1;
+  vr cp[3] = {ldsv(sh.cpos, c * 3), ldsv(sh.cpos, c * 3 + 1), ldsv(sh.cpos, c * 3 + 2)};
+  vr dist = ldsv(sh.cdist, c);
+  V<int> L = ldsv(sh.cleg, c);
+  const VB onleg = L >= 0;
+  const V<int> Lc = vmax(L, V<int>(0));
+  // pyramid edge direction for the floor frame n=(0,0,1), t1=(0,1,0), t2=(-1,0,0): d = n +- mu t_k
+  vr smu = sel(sg == 0, vr(M.mu), vr(-M.mu));
+  vr d[3];
+  d[0] = sel(tk == 1, -smu, vr(real(0)));
+  d[1] = sel(tk == 0, smu, vr(real(0)));
+  d[2] = vr(real(1));
+  // Jacobian row: base translation, base rotation (body axes), the 3 hinges of the contact's own leg
+  vr Jb[6], Jl[3];
+  {
+    vr m[3];
+    cross3(m, cp, d);  // (p - O) x d
+    Jb[0] = d[0]; Jb[1] = d[1]; Jb[2] = d[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Jb[3 + j] = sh.Rb[j] * m[0] + sh.Rb[3 + j] * m[1] + sh.Rb[6 + j] * m[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vr a[3], r[3], rel[3], mm[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        a[j] = ldsv(sh.axs, Lc * 9 + (3 * k + j));
+        r[j] = ldsv(sh.anc, Lc * 9 + (3 * k + j));
+        rel[j] = cp[j] - r[j];
+      }
+      cross3(mm, rel, d);
+      Jl[k] = sel(onleg, dot3<vr>(a, mm), vr(real(0)));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) Jb[j] = sel(act, Jb[j], vr(real(0)));
+#pragma unroll
+  for (int k = 0; k < 3; k++) Jl[k] = sel(act, Jl[k], vr(real(0)));
+  // publish the sparse row for the projection sweep
+#pragma unroll
+  for (int j = 0; j < 6; j++) stsv(sh.jrow, lane * kJRow + j, Jb[j], lane < kMaxRow);
+#pragma unroll
+  for (int k = 0; k < 3; k++) stsv(sh.jrow, lane * kJRow + (6 + k), Jl[k], lane < kMaxRow);
+  stsv(sh.jrow, lane * kJRow + 9, to_real<real>(L), lane < kMaxRow);
+
+  // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
+  vr imp;
+  {
+    vr x = vabs(dist) / M.si_width;
+    vr ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
+    vr yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
+    vr y = sel(x <= vr(M.si_mid), ylo, yhi);
+    imp = M.si_d0 + y * (M.si_dmax - M.si_d0);
+    imp = sel(x >= vr(real(1)), vr(M.si_dmax), imp);
+    imp = sel(x <= vr(real(0)), vr(M.si_d0), imp);
+  }
+  vr invw = gldv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
+  vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
+  vr Dd = vr(real(1)) / Rr;
+  // sparse dots with the wave-uniform vectors qvel, qacc_smooth, qacc_warmstart
+  vr vel = vr(real(0)), jas = vr(real(0)), jaw = vr(real(0));
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vel += Jb[j] * sh.qvel[j]; jas += Jb[j] * sh.qas[j]; jaw += Jb[j] * sh.warm[j];
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    V<int> di = Lc * 3 + (6 + k);
+    vel += Jl[k] * ldsv(sh.qvel, di); jas += Jl[k] * ldsv(sh.qas, di); jaw += Jl[k] * ldsv(sh.warm, di);
+  }
+  vr aref = -M.solref_B * vel - M.solref_K * imp * dist;
+  vr bb = jas - aref;
+
+  // B = M^-1 J' for this row (block factor; W/Minv of the row's own leg gathered per lane)
+  vr B[24];
+  {
+    vr t[3], Mi[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) Mi[j] = ldsv(sh.Minv, Lc * 6 + j);
+    ldl3_solve(t, Mi, Jl);
+    vr xb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      xb[j] = Jb[j];
+#pragma unroll
+      for (int k = 0; k < 3; k++) xb[j] = xb[j] - ldsv(sh.W, Lc * 18 + (6 * k + j)) * Jl[k];
+    }
+    ldl6_solve(sh.Lb, sh.Dbi, xb);
+#pragma unroll
+    for (int j = 0; j < 6; j++) B[j] = xb[j];
+#pragma unroll
+    for (int l = 0; l < 6; l++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        vr x = sel(L == l, t[k], vr(real(0)));
+#pragma unroll
+        for (int j = 0; j < 6; j++) x = x - sh.W[l * 18 + 6 * k + j] * xb[j];
+        B[6 + 3 * l + k] = x;
+      }
+  }
+  wave_sync();
+  // A[i] (in lane j) = J_i . B_j  -> lane j holds row j of the symmetric A = J M^-1 J'
+  vr A[kMaxRow];
+#pragma unroll
+  for (int i = 0; i < kMaxRow; i++) {
+    A[i] = vr(real(0));
+    if (i < nefc) {
+      const real* jr = sh.jrow + i * kJRow;
+      vr a = jr[0] * B[0] + jr[1] * B[1] + jr[2] * B[2] + jr[3] * B[3] + jr[4] * B[4] + jr[5] * B[5];
+      const int Li = uniform((int)jr[9]);
+      switch (Li) {
+        case 0: a += jr[6] * B[6] + jr[7] * B[7] + jr[8] * B[8]; break;
+        case 1: a += jr[6] * B[9] + jr[7] * B[10] + jr[8] * B[11]; break;
+        case 2: a += jr[6] * B[12] + jr[7] * B[13] + jr[8] * B[14]; break;
+        case 3: a += jr[6] * B[15] + jr[7] * B[16] + jr[8] * B[17]; break;
+        case 4: a += jr[6] * B[18] + jr[7] * B[19] + jr[8] * B[20]; break;
+        case 5: a += jr[6] * B[21] + jr[7] * B[22] + jr[8] * B[23]; break;
+        default: break;
+      }
+      A[i] = a;
+    }
+  }
+  // own diagonal entry (needed as 1/AR_ii): A_jj = J_j . B_j
+  vr Ajj = Jb[0] * B[0] + Jb[1] * B[1] + Jb[2] * B[2] + Jb[3] * B[3] + Jb[4] * B[4] + Jb[5] * B[5];
+#pragma unroll
+  for (int l = 0; l < 6; l++) Ajj += sel(L == l, Jl[0] * B[6 + 3 * l] + Jl[1] * B[7 + 3 * l] + Jl[2] * B[8 + 3 * l], vr(real(0)));
+  vr ARjj = Ajj + Rr;
+  vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
+
+  // ---- warm start (PGS branch of mj_fwdConstraint): f from qacc_warmstart, kept only if its dual cost < 0
+  vr jar = jaw - aref;
+  vr f = sel(act & (jar < vr(real(0))), -Dd * jar, vr(real(0)));
+  vr g = bb;  // g_j = (A f)_j + b_j  (residual without the R term)
+#pragma unroll
+  for (int i = 0; i < kMaxRow; i++)
+    if (i < nefc) g += A[i] * rdlane(f, i);
+  {
+    real cost = wsum<real>(sel(act, f * (bb + real(0.5) * (g - bb + Rr * f)), vr(real(0))));
+    if (cost > real(0)) { f = vr(real(0)); g = bb; }
+  }
+#ifdef NM_DEBUG_SOLVER
+  stsv(sh.dbg_b, lane, bb, lane < kMaxRow); stsv(sh.dbg_a, lane, ARjj, lane < kMaxRow); stsv(sh.dbg_f0, lane, f, lane < kMaxRow);
+#endif
+  // ---- mj_solPGS: Gauss-Seidel over rows; every lane keeps its residual current by a rank-1 update
+  for (int iter = 0; iter < M.pgs_iters; iter++) {
+    real improvement = real(0);
+#pragma unroll
+    for (int i = 0; i < kMaxRow; i++) {
+      if (i < nefc) {
+        vr res = g + Rr * f;
+        vr fn = vmax(f - res * ARinv, vr(real(0)));
+        vr dl = fn - f;
+        vr change = real(0.5) * dl * dl * ARjj + dl * res;
+        VB bad = change > vr(real(1e-10));
+        dl = sel(bad, vr(real(0)), dl);
+        change = sel(bad, vr(real(0)), change);
+        real di = rdlane(dl, i);
+        improvement = improvement - rdlane(change, i);
+        g += A[i] * di;
+        f = wrlane(f, rdlane(f + dl, i), i);
+      }
+    }
+    sh.it_pgs = iter + 1;
+    if (improvement * M.pgs_scale < M.pgs_tol) break;
+  }
+  // ---- mj_solNoSlip: per opposing pyramid pair, exact 1-D minimisation along (f0 - f1) without R
+  for (int iter = 0; iter < M.noslip_iters; iter++) {
+    real improvement = real(0);
+    if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
+#pragma unroll
+    for (int p = 0; p < kMaxRow / 2; p++) {
+      if (2 * p < nefc) {
+        const int j0 = 2 * p, j1 = 2 * p + 1;
+        real Ac0 = rdlane(A[j0], j0), Ac1 = rdlane(A[j1], j0), Ac3 = rdlane(A[j1], j1);
+        real r0 = rdlane(g, j0), r1 = rdlane(g, j1), o0 = rdlane(f, j0), o1 = rdlane(f, j1);
+        real bc0 = r0 - Ac0 * o0 - Ac1 * o1, bc1 = r1 - Ac1 * o0 - Ac3 * o1;
+        real mid = real(0.5) * (o0 + o1);
+        real K1 = Ac0 + Ac3 - Ac1 - Ac1, K0 = mid * (Ac0 - Ac3) + bc0 - bc1;
+        real n0, n1;
+        if (K1 < real(1e-15)) { n0 = mid; n1 = mid; }
+        else {
+          real y = -K0 / K1;
+          if (y < -mid) { n0 = real(0); n1 = real(2) * mid; }
+          else if (y > mid) { n0 = real(2) * mid; n1 = real(0); }
+          else { n0 = mid + y; n1 = mid - y; }
+        }
+        real d0 = n0 - o0, d1 = n1 - o1;
+        real change = real(0.5) * (d0 * (Ac0 * d0 + Ac1 * d1) + d1 * (Ac1 * d0 + Ac3 * d1)) + d0 * r0 + d1 * r1;
+        if (change > real(1e-10)) { d0 = real(0); d1 = real(0); change = real(0); }
+        improvement = improvement - change;
+        g += A[j0] * d0 + A[j1] * d1;
+        f = wrlane(f, o0 + d0, j0);
+        f = wrlane(f, o1 + d1, j1);
+      }
+    }
+    sh.it_noslip = iter + 1;
+    if (improvement * M.pgs_scale < M.noslip_tol) break;
+  }
+  stsv(sh.efc_f, lane, f, lane < kMaxRow);
+  // ---- qfrc_constraint = J' f
+#pragma unroll
+  for (int j = 0; j < 6; j++) sh.qfc[j] = wsum<real>(Jb[j] * f);
+#pragma unroll
+  for (int l = 0; l < 6; l++)
+#pragma unroll
+    for (int k = 0; k < 3; k++) sh.qfc[6 + 3 * l + k] = wsum<real>(sel(L == l, Jl[k] * f, vr(real(0))));
+  // ---- touch sensors (only the last forward pass is observable after mj_step)
+  if (last) {
+    vr nf = f + shfl_xor(f, 1);
+    nf = nf + shfl_xor(nf, 2);  // contact normal force = sum of its 4 pyramid edge forces
+    VB head = act & ((lane & 3) == 0) & (nf > vr(real(0)));
+    // foot site sphere: ray from the contact point along -normal must hit it
+    vr ft[3], fr;
+    {
+      vr s[3], Rt[9];
+#pragma unroll
+      for (int j = 0; j < 3; j++) s[j] = gldv(M.footc, Lc * 4 + j);
+      fr = gldv(M.footc, Lc * 4 + 3);
+#pragma unroll
+      for (int j = 0; j < 9; j++) Rt[j] = ldsv(sh.colR, (Lc + 1) * 9 + j);
+      matvec3(ft, Rt, s);
+#pragma unroll
+      for (int j = 0; j < 3; j++) ft[j] = ft[j] + ldsv(sh.colp, (Lc + 1) * 3 + j);
+    }
+    vr dif[3] = {cp[0] - ft[0], cp[1] - ft[1], cp[2] - ft[2]};
+    vr b2 = -dif[2], cc = dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2] - fr * fr;
+    vr det = b2 * b2 - cc;
+    vr sq = vsqrt(vmax(det, vr(real(0))));
+    VB hit = !(det < vr(real(1e-15))) & (((-b2 - sq) >= vr(real(0))) | ((-b2 + sq) >= vr(real(0))));
+#pragma unroll
+    for (int l = 0; l < 6; l++) {
+      sh.sens[l] = wsum<real>(sel(head & (L == l), nf, vr(real(0))));          // tibia sites: 10 m spheres see every contact
+      sh.sens[6 + l] = wsum<real>(sel(head & (L == l) & hit, nf, vr(real(0))));  // foot sites
+    }
+    sh.sens[12] = wsum<real>(sel(head & (L < 0), nf, vr(real(0))));
+  }
+  wave_sync();
+}
+
+// =========================================================================================  stage D
+// qacc (for the warm start), implicitfast velocity update, position integration. Returns "qacc is bad".
+template <class real> NM_FN bool stage_integrate(Sh<real>& sh, const Model<real>& M) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const V<int> leg = lane % 6;
+  const VB isleg = lane < 6;
+  vr qacc_l[3], qint_l[3];
+  real qacc_b[6], qint_b[6];
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {
+    // pass 0: qacc = qacc_smooth + M^-1 qfrc_constraint ; pass 1: (M + h kv I) qacc_int = qfrc_smooth + qfrc_constraint
+    const real* shMinv = pass ? sh.MinvH : sh.Minv;
+    const real* shW = pass ? sh.WH : sh.W;
+    const real* shL = pass ? sh.LbH : sh.Lb;
+    const real* shD = pass ? sh.DbiH : sh.Dbi;
+    vr y[3], t[3], Mi[6];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      y[k] = ldsv(sh.qfc, leg * 3 + (6 + k));
+      if (pass) y[k] = y[k] + ldsv(sh.qfs, leg * 3 + (6 + k));
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) Mi[j] = ldsv(shMinv, leg * 6 + j);
+    ldl3_solve(t, Mi, y);
+    real xb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      vr wy = ldsv(shW, leg * 18 + j) * y[0] + ldsv(shW, leg * 18 + (6 + j)) * y[1] + ldsv(shW, leg * 18 + (12 + j)) * y[2];
+      xb[j] = sh.qfc[j] + (pass ? sh.qfs[j] : real(0)) - lanesum6<real>(wy);
+    }
+    ldl6_solve(shL, shD, xb);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vr x = t[k];
+#pragma unroll
+      for (int j = 0; j < 6; j++) x = x - ldsv(shW, leg * 18 + (6 * k + j)) * xb[j];
+      if (pass) qint_l[k] = x; else qacc_l[k] = x + ldsv(sh.qas, leg * 3 + (6 + k));
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) { if (pass) qint_b[j] = xb[j]; else qacc_b[j] = xb[j] + sh.qas[j]; }
+  }
+  // mj_checkAcc
+  VB badv = visbad(qacc_l[0]) | visbad(qacc_l[1]) | visbad(qacc_l[2]);
+  bool bad = wany(badv & isleg);
+#pragma unroll
+  for (int j = 0; j < 6; j++) bad = bad | visbad(qacc_b[j]);
+  if (bad) return true;
+  wave_sync();
+  // mj_advance: qacc_warmstart <- qacc ; qvel += h qacc_int ; qpos integrates the NEW velocity
+  real nv[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    nv[j] = sh.qvel[j] + M.h * qint_b[j];
+    sh.warm[j] = qacc_b[j];
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) sh.qvel[j] = nv[j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) sh.qpos[j] = sh.qpos[j] + M.h * nv[j];
+  {  // mju_quatIntegrate: q <- q * exp(h w), w in the body frame
+    real ax[3] = {nv[3], nv[4], nv[5]};
+    real n = vsqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
+    real qr[4] = {real(1), real(0), real(0), real(0)};
+    if (n >= real(1e-15)) {
+      real ang = M.h * n, s, c;
+      vsincos(real(0.5) * ang, &s, &c);
+      if (ang != real(0)) { qr[0] = c; qr[1] = ax[0] / n * s; qr[2] = ax[1] / n * s; qr[3] = ax[2] / n * s; }
+    }
+    real a[4] = {sh.qpos[3], sh.qpos[4], sh.qpos[5], sh.qpos[6]};
+    real t[4] = {a[0] * qr[0] - a[1] * qr[1] - a[2] * qr[2] - a[3] * qr[3], a[0] * qr[1] + a[1] * qr[0] + a[2] * qr[3] - a[3] * qr[2],
+                 a[0] * qr[2] - a[1] * qr[3] + a[2] * qr[0] + a[3] * qr[1], a[0] * qr[3] + a[1] * qr[2] - a[2] * qr[1] + a[3] * qr[0]};
+    real nn = vsqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);  // mj_kinematics normalises before use
+    sh.qpos[3] = t[0] / nn; sh.qpos[4] = t[1] / nn; sh.qpos[5] = t[2] / nn; sh.qpos[6] = t[3] / nn;
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    V<int> di = leg * 3 + (6 + k);
+    vr qd = ldsv(sh.qvel, di) + M.h * qint_l[k];
+    vr q = ldsv(sh.qpos, di + 1) + M.h * qd;
+    stsv(sh.qvel, di, qd, isleg);
+    stsv(sh.qpos, di + 1, q, isleg);
+    stsv(sh.warm, di, qacc_l[k], isleg);
+  }
+  wave_sync();
+  return false;
+}
+
+template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) {  // mj_resetData
+  const V<int> lane = lane_id();
+  stsv(sh.qpos, lane, gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
+  stsv(sh.qvel, lane, real(0), lane < kNV);
+  stsv(sh.warm, lane, real(0), lane < kNV);
+  stsv(sh.ctrl, lane, real(0), lane < kNU);
+  wave_sync();
+}
+
+// mj_step(model, data, 1)
+template <class real> NM_FN void substep(Sh<real>& sh, const Model<real>& M, bool last, int* dropped) {
+  const V<int> lane = lane_id();
+  {  // mj_checkPos / mj_checkVel
+    VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
+             (visbad(ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0)))) & (lane < kNV));
+    if (wany(bad)) { sh.nwarn += 1; reset_data(sh, M); }
+  }
+  {  // mj_kinematics normalises the free joint's quaternion in qpos
+    real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
+    real a = sh.qpos[3] / n, b = sh.qpos[4] / n, c = sh.qpos[5] / n, d = sh.qpos[6] / n;
+    wave_sync();
+    sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
+    wave_sync();
+  }
+  for (int attempt = 0; attempt < 2; attempt++) {
+    stage_smooth(sh, M, last);
+    stage_collide(sh, M, dropped);
+    stage_constraint(sh, M, last);
+    bool bad = stage_integrate(sh, M);
+    if (!bad) break;
+    sh.nwarn += 1;  // mj_checkAcc: reset, run the forward pass again, integrate
+    reset_data(sh, M);
+  }
+}
+
+// =========================================================================================  env step
+template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const VB l18 = lane < kNU;
+  const V<int> l18c = sel(l18, lane, V<int>(0));
+  // ---- load state
+  stsv(sh.qpos, lane, gldv(A.qpos, sel(lane < kNQ, lane, V<int>(0)) + env * kNQ), lane < kNQ);
+  stsv(sh.qvel, lane, gldv(A.qvel, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
+  stsv(sh.warm, lane, gldv(A.qwarm, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
+  sh.nwarn = 0;
+  // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
+  V<float> a_in = gldv(A.actions, l18c + env * kNU);
+  V<float> af = a_in * M.action_scale;
+  af = vmin(vmax(af, V<float>(-M.clip_actions)), V<float>(M.clip_actions));
+  vr act, prev_act, prev_dofvel, dofpos_old;
+  vr defp;
+  {
+    V<int> m3 = lane % 3;
+    defp = sel(m3 == 1, vr(M.default_pos[1]), sel(m3 == 0, vr(M.default_pos[0]), vr(M.default_pos[2])));
+  }
+#ifdef NM_EMUL
+  for (int i = 0; i < NM_WAVE; i++) act.v[i] = (real)af.v[i];
+#else
+  act = (real)af;
+#endif
+  if (!A.physics_only) {
+    prev_act = gldv(A.act, l18c + env * kNU);
+    prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
+    dofpos_old = gldv(A.dofpos, l18c + env * kNU);
+    stsv(sh.ctrl, lane, ((act - defp) - dofpos_old) * M.p_gain, l18);
+  } else {  // dynamics-only mode (BASELINE config 2): same PD law on the current joint angles, no env buffers
+    stsv(sh.ctrl, lane, ((act - defp) - ldsv(sh.qpos, l18c + 7)) * M.p_gain, l18);
+  }
+  wave_sync();
+  // ---- E2 (env.py:200): mj_step(model, data, decimation)
+  int dropped = 0;
+  for (int s = 0; s < A.nsub; s++) substep(sh, M, s == A.nsub - 1, &dropped);
+  // ---- store physics state
+  gstv(A.qpos, lane + env * kNQ, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
+  gstv(A.qvel, lane + env * kNV, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
+  gstv(A.qwarm, lane + env * kNV, ldsv(sh.warm, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
+  if (A.dbg) {
+    real* dbg = A.dbg + (size_t)env * kDbgN;
+    gstv(dbg, lane, ldsv(sh.qas, sel(lane < 24, lane, V<int>(0))), lane < 24);
+    gstv(dbg, lane + 24, ldsv(sh.qfs, sel(lane < 24, lane, V<int>(0))), lane < 24);
+    gstv(dbg, lane + 48, ldsv(sh.qfc, sel(lane < 24, lane, V<int>(0))), lane < 24);
+    gstv(dbg, lane + 72, ldsv(sh.sens, sel(lane < 13, lane, V<int>(0))), lane < 13);
+    gstv(dbg, lane + 88, ldsv(sh.cvb, sel(lane < 6, lane, V<int>(0))), lane < 6);
+    gstv(dbg, lane + 96, ldsv(sh.cdist, sel(lane < kMaxCon, lane, V<int>(0))), lane < kMaxCon);
+    gstv(dbg, lane + 112, ldsv(sh.cpos, sel(lane < 3 * kMaxCon, lane, V<int>(0))), lane < 3 * kMaxCon);
+    gstv(dbg, V<int>(160), to_real<real>(sh.ncon), lane == 0);
+    gstv(dbg, V<int>(161), to_real<real>(sh.nwarn), lane == 0);
+    gstv(dbg, V<int>(162), to_real<real>(dropped), lane == 0);
+    gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
+    gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
+    gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);
+#ifdef NM_DEBUG_SOLVER
+    gstv(dbg, lane + 240, ldsv(sh.dbg_b, sel(lane < 4, lane, V<int>(0))), lane < 4);
+    gstv(dbg, lane + 244, ldsv(sh.dbg_a, sel(lane < 4, lane, V<int>(0))), lane < 4);
+    gstv(dbg, lane + 248, ldsv(sh.dbg_f0, sel(lane < 4, lane, V<int>(0))), lane < 4);
+#endif
+  }
+  if ((dropped | sh.nwarn) && A.stat_cnt) {
+#ifdef NM_EMUL
+    A.stat_cnt[1] += dropped; A.stat_cnt[2] += sh.nwarn;
+#else
+    if (threadIdx.x == 0) { atomicAdd(A.stat_cnt + 1, dropped); atomicAdd(A.stat_cnt + 2, sh.nwarn); }
+#endif
+  }
+  if (A.physics_only) return;
+
+  // ---- E3 (env.py:212-232): frame transforms with the POST-integration quaternion, stale cvel/sensors
+  int64_t eplen = A.eplen[env] + 1;
+  real bq[4] = {sh.qpos[3], -sh.qpos[4], -sh.qpos[5], -sh.qpos[6]};  // mju_negQuat
+  auto rot = [&](real* r, const real* v) {  // mju_rotVecQuat
+    real tx = real(2) * (bq[2] * v[2] - bq[3] * v[1]), ty = real(2) * (bq[3] * v[0] - bq[1] * v[2]), tz = real(2) * (bq[1] * v[1] - bq[2] * v[0]);
+    r[0] = v[0] + bq[0] * tx + (bq[2] * tz - bq[3] * ty);
+    r[1] = v[1] + bq[0] * ty + (bq[3] * tx - bq[1] * tz);
+    r[2] = v[2] + bq[0] * tz + (bq[1] * ty - bq[2] * tx);
+  };
+  real blv[3], bav[3], pg[3];
+  {
+    real lin[3] = {sh.cvb[3], sh.cvb[4], sh.cvb[5]}, ang[3] = {sh.cvb[0], sh.cvb[1], sh.cvb[2]}, gv[3] = {real(0), real(0), -M.grav};
+    rot(blv, lin); rot(bav, ang); rot(pg, gv);
+  }
+  vr dofpos = ldsv(sh.qpos, l18c + 7), dofvel = ldsv(sh.qvel, l18c + 6);
+  real tib[6], feet[6], body = sh.sens[12];
+#pragma unroll
+  for (int l = 0; l < 6; l++) {
+    feet[l] = sh.sens[6 + l];
+    tib[l] = feet[l] == real(0) ? sh.sens[l] : real(0);  // env.py:232
+  }
+  // ---- E4 (env.py:235-236, 321-333): periodic command resample
+  real cmd[3] = {A.cmd[env * 3], A.cmd[env * 3 + 1], A.cmd[env * 3 + 2]};
+  uint32_t ctr = A.rngctr[env];
+  auto resample = [&](int which) {
+    real ux, uy;
+    if (A.cmd_u) { ux = A.cmd_u[env * 4 + 2 * which]; uy = A.cmd_u[env * 4 + 2 * which + 1]; }
+    else {
+      ux = (real)rand_u24_bits(A.seed, (uint64_t)(A.env_offset + env), ctr) * real(1.0 / 16777216.0);
+      uy = (real)rand_u24_bits(A.seed, (uint64_t)(A.env_offset + env), ctr + 1) * real(1.0 / 16777216.0);
+      ctr += 2;
+    }
+    cmd[0] = ux * real(2) * M.max_lin_x - M.max_lin_x;
+    cmd[1] = real(0);
+    cmd[2] = uy * real(2) * M.max_ang - M.max_ang;
+    real keep = vsqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > real(0.02) ? real(1) : real(0);
+    cmd[0] = cmd[0] * keep; cmd[1] = cmd[1] * keep;
+  };
+  if (eplen % M.resample_every == 0) resample(0);
+  // ---- E5 (env.py:239-258): termination
+  bool time_out = (real)eplen > M.max_ep_len;
+  bool reset = time_out;
+  {
+    real fm = feet[0];
+#pragma unroll
+    for (int l = 1; l < 6; l++) fm = vmax(fm, feet[l]);
+    reset = reset | (fm > M.term_force);
+    real nrm = vsqrt(pg[0] * pg[0] + pg[1] * pg[1] + pg[2] * pg[2]);
+    reset = reset | (vacos(-pg[2] / nrm) > real(1.0471975511965976));  // 60 deg
+  }
+  // ---- E6 (env.py:274, 335-371): reset BEFORE rewards/obs: qpos0, zero velocity, new command, episode stats
+  vr epsum[1];
+  V<int> l8c = sel(lane < kNREW, lane, V<int>(0));
+  epsum[0] = gldv(A.epsum, l8c + env * kNREW);
+  if (reset) {
+    gstv(A.qpos, lane + env * kNQ, gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
+    gstv(A.qvel, lane + env * kNV, real(0), lane < kNV);
+    resample(1);
+    eplen = 0;
+#ifdef NM_EMUL
+    for (int k = 0; k < kNREW; k++) A.stat_sum[k] += epsum[0].v[k];
+    A.stat_cnt[0] += 1;
+#else
+    if (threadIdx.x < kNREW) atomicAdd(A.stat_sum + threadIdx.x, epsum[0]);
+    if (threadIdx.x == 0) atomicAdd(A.stat_cnt, 1);
+#endif
+    epsum[0] = vr(real(0));
+  }
+  // ---- E7 (env.py:277-288, 399-497): rewards (alphabetical, termination last)
+  real rt[kNREW];
+  {
+    vr da = prev_act - act;
+    rt[R_ACTION_RATE] = wsum<real>(sel(l18, da * da, vr(real(0)))) * M.rew_scale[R_ACTION_RATE];
+    real sumt = ((tib[0] + tib[1]) + (tib[2] + tib[3])) + (tib[4] + tib[5]);
+    rt[R_BODY_CONTACT] = (sumt + body) * M.rew_scale[R_BODY_CONTACT];
+    vr dp = dofpos - defp;
+    rt[R_DEFAULT_POS] = wsum<real>(sel(l18, dp * dp, vr(real(0)))) * M.rew_scale[R_DEFAULT_POS];
+    vr acc = (dofvel - prev_dofvel) / M.dt;
+    rt[R_DOF_ACC] = wsum<real>(sel(l18, acc * acc, vr(real(0)))) * M.rew_scale[R_DOF_ACC];
+    rt[R_ORIENTATION] = (pg[0] * pg[0] + pg[1] * pg[1]) * M.rew_scale[R_ORIENTATION];
+    real ea = (cmd[2] - bav[2]) * (cmd[2] - bav[2]);
+    rt[R_TRACK_ANG] = vexp(-ea / M.sigma) * M.rew_scale[R_TRACK_ANG];
+    real el = (cmd[0] - blv[0]) * (cmd[0] - blv[0]) + (cmd[1] - blv[1]) * (cmd[1] - blv[1]);
+    rt[R_TRACK_LIN] = vexp(-el / M.sigma) * M.rew_scale[R_TRACK_LIN];
+    rt[R_TERMINATION] = (reset && !time_out) ? M.rew_scale[R_TERMINATION] : real(0);
+  }
+  real rew = real(0);
+#pragma unroll
+  for (int k = 0; k < kNREW; k++) rew = rew + rt[k];
+  {
+    vr add = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < kNREW; k++) add = wrlane(add, rt[k], k);
+    gstv(A.epsum, lane + env * kNREW, epsum[0] + add, lane < kNREW);
+  }
+  // ---- E8 (env.py:291-311): observation (66), clipped, float32
+  {
+    real head[12] = {blv[0] * M.obs_lin, blv[1] * M.obs_lin, blv[2] * M.obs_lin, bav[0] * M.obs_ang, bav[1] * M.obs_ang, bav[2] * M.obs_ang,
+                     pg[0], pg[1], pg[2], cmd[0] * M.obs_lin, cmd[1] * M.obs_lin, cmd[2] * M.obs_ang};
+    vr o = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < 12; k++) o = wrlane(o, head[k], k);
+    auto put = [&](const vr& x, const V<int>& idx, const VB& m) {
+      vr cx = vmin(vmax(x, vr(-M.clip_obs)), vr(M.clip_obs));
+#ifdef NM_EMUL
+      for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) A.obs[(size_t)env * kNOBS + idx.v[i]] = (float)cx.v[i];
+#else
+      if (m) A.obs[(size_t)env * kNOBS + idx] = (float)cx;
+#endif
+    };
+    put(o, lane, lane < 12);
+    put((dofpos - defp) * M.obs_dofpos, lane + 12, l18);
+    put(dofvel * M.obs_dofvel, lane + 30, l18);
+    put(act, lane + 48, l18);
+  }
+  // ---- buffers the reference keeps between steps
+  gstv(A.dofpos, lane + env * kNU, dofpos, l18);
+  gstv(A.dofvel, lane + env * kNU, dofvel, l18);
+  gstv(A.act, lane + env * kNU, act, l18);
+  {
+    vr cv = sel(lane == 0, vr(cmd[0]), sel(lane == 1, vr(cmd[1]), vr(cmd[2])));
+    gstv(A.cmd, lane + env * 3, cv, lane < 3);
+  }
+#ifdef NM_EMUL
+  const bool lane0 = true;
+#else
+  const bool lane0 = threadIdx.x == 0;
+#endif
+  if (lane0) {
+    A.eplen[env] = eplen;
+    A.rngctr[env] = ctr;
+    A.rew[env] = (float)rew;
+    A.done[env] = reset ? 1 : 0;
+    A.timeout_now[env] = time_out ? 1.0f : 0.0f;
+  }
+}
+
+}  // namespace nm

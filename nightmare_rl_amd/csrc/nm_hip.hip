@@ -1,0 +1,347 @@
+// nm_hip.hip - gfx950 kernels + the C ABI of include/nightmare_hip.h. Device-only: there is no CPU path.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nightmare_hip.h"
+#include "nm_host_model.h"
+
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+#define HIPCHK(x)                                                                                        \
+  do {                                                                                                   \
+    hipError_t e_ = (x);                                                                                 \
+    if (e_ != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(e_));                  \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------------ kernels
+// One 64-lane wavefront per env, one wave per workgroup: LDS image private to the wave, no inter-wave sync.
+#ifndef NM_WAVES_PER_SIMD
+#define NM_WAVES_PER_SIMD 4
+#endif
+template <class real>
+__global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
+  __shared__ nm::Sh<real> sh;
+  const int env = blockIdx.x;
+  if (env >= A.N) return;
+  nm::env_step(sh, *Mp, A, env);
+}
+
+// reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
+template <class real>
+__global__ void k_reset(nm::Model<real> M, nm::Args<real> A, const int32_t* ids, int n) {
+  int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  int env = ids ? ids[j] : j;
+  for (int k = 0; k < nm::kNQ; k++) A.qpos[env * nm::kNQ + k] = M.qpos0[k];
+  for (int k = 0; k < nm::kNV; k++) A.qvel[env * nm::kNV + k] = real(0);
+  real ux, uy;
+  uint32_t ctr = A.rngctr[env];
+  if (A.cmd_u) { ux = A.cmd_u[env * 4 + 2]; uy = A.cmd_u[env * 4 + 3]; }
+  else {
+    ux = (real)nm::rand_u24_bits(A.seed, (uint64_t)(A.env_offset + env), ctr) * real(1.0 / 16777216.0);
+    uy = (real)nm::rand_u24_bits(A.seed, (uint64_t)(A.env_offset + env), ctr + 1) * real(1.0 / 16777216.0);
+    ctr += 2;
+  }
+  real c0 = ux * real(2) * M.max_lin_x - M.max_lin_x, c2 = uy * real(2) * M.max_ang - M.max_ang;
+  real keep = sqrt(c0 * c0) > real(0.02) ? real(1) : real(0);
+  A.cmd[env * 3] = c0 * keep; A.cmd[env * 3 + 1] = real(0); A.cmd[env * 3 + 2] = c2;
+  A.rngctr[env] = ctr;
+  A.eplen[env] = 0;
+  for (int k = 0; k < nm::kNREW; k++) {
+    atomicAdd(A.stat_sum + k, A.epsum[env * nm::kNREW + k]);
+    A.epsum[env * nm::kNREW + k] = real(0);
+  }
+  atomicAdd(A.stat_cnt, 1);
+}
+
+// extras: like the reference, 'episode' and 'time_outs' are refreshed only when >= 1 env reset (env.py:344-371).
+// Single workgroup, so it can clear the accumulators after everyone has read them.
+template <class real>
+__global__ void k_finalize(int N, real* stat_sum, int* stat_cnt, float* ep_stats, const float* timeout_now, float* time_outs,
+                           real ep_len_s, long long* counters) {
+  __shared__ int cnt;
+  if (threadIdx.x == 0) cnt = stat_cnt[0];
+  __syncthreads();
+  if (cnt > 0) {
+    if (threadIdx.x < nm::kNREW && ep_stats) ep_stats[threadIdx.x] = (float)(stat_sum[threadIdx.x] / (real)cnt / ep_len_s);
+    if (time_outs && timeout_now)
+      for (int i = threadIdx.x; i < N; i += blockDim.x) time_outs[i] = timeout_now[i];
+  }
+  __syncthreads();
+  if (threadIdx.x < nm::kNREW) stat_sum[threadIdx.x] = real(0);
+  if (threadIdx.x == 0) {
+    stat_cnt[0] = 0;
+    counters[0] += stat_cnt[1];
+    counters[1] += stat_cnt[2];
+    stat_cnt[1] = 0;
+    stat_cnt[2] = 0;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ host object
+struct nm_env {
+  int N = 0, device = 0, dtype = 0;
+  virtual ~nm_env() {}
+  virtual int reset(const int32_t* ids, int n, int64_t* eplen, float* ep_stats, hipStream_t s) = 0;
+  virtual int step(const float* actions, int64_t* eplen, float* obs, float* rew, int64_t* done, float* time_outs, float* ep_stats,
+                   int physics_only, hipStream_t s) = 0;
+  virtual int get_state(double* qpos, double* qvel, double* qw) = 0;
+  virtual int set_state(const double* qpos, const double* qvel, const double* qw) = 0;
+  virtual int get_buffers(double* dp, double* dv, double* act, double* cmd, double* es) = 0;
+  virtual int set_buffers(const double* dp, const double* dv, const double* act, const double* cmd, const double* es) = 0;
+  virtual int set_cmd_u(const double* u) = 0;
+  virtual int counters(int64_t* out) = 0;
+  virtual void set_dbg(void* p) = 0;
+  virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
+};
+
+template <class real> struct Env : nm_env {
+  nmhost::Tables<real> T;
+  nm::Model<real> M;
+  nm::Args<real> A;
+  std::vector<void*> allocs;
+  real* cmd_u_dev = nullptr;
+  bool cmd_u_on = false;
+  float* timeout_now = nullptr;
+  int32_t* ids_dev = nullptr;
+  long long* counters_dev = nullptr;
+  nm::Model<real>* M_dev = nullptr;
+  bool prof_on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
+  size_t prof_used = 0;
+
+  template <class X> int dalloc(X** p, size_t n) {
+    HIPCHK(hipMalloc((void**)p, n * sizeof(X)));
+    HIPCHK(hipMemset(*p, 0, n * sizeof(X)));
+    allocs.push_back(*p);
+    return 0;
+  }
+  template <class X> int upload(const X** p, const std::vector<X>& v) {
+    X* d;
+    if (dalloc(&d, v.size())) return 1;
+    HIPCHK(hipMemcpy(d, v.data(), v.size() * sizeof(X), hipMemcpyHostToDevice));
+    *p = d;
+    return 0;
+  }
+  int init(const nmhost::EnvConfig& cfg, int n, int dev, uint64_t seed, int64_t off) {
+    N = n; device = dev; dtype = sizeof(real) == 8;
+    HIPCHK(hipSetDevice(dev));
+    T.build();
+    memset(&M, 0, sizeof M);
+    memset(&A, 0, sizeof A);
+    T.fill_scalars(M, cfg);
+    if (upload(&M.legc, T.legc) || upload(&M.basec, T.basec) || upload(&M.colc, T.colc) || upload(&M.hullv, T.hullv) ||
+        upload(&M.hullnbr, T.hullnbr) || upload(&M.footc, T.footc) || upload(&M.qpos0, T.qpos0))
+      return 1;
+    A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
+    size_t n_ = (size_t)N;
+    if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
+        dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * 8) ||
+        dalloc(&A.rngctr, n_) || dalloc(&A.stat_sum, 8) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 2))
+      return 1;
+    if (dalloc(&M_dev, 1)) return 1;
+    HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));
+    std::vector<real> q0(n_ * 25);
+    for (size_t i = 0; i < n_; i++)
+      for (int k = 0; k < 25; k++) q0[i * 25 + k] = T.qpos0[k];
+    HIPCHK(hipMemcpy(A.qpos, q0.data(), q0.size() * sizeof(real), hipMemcpyHostToDevice));
+    return 0;
+  }
+  ~Env() override {
+    for (void* p : allocs) (void)hipFree(p);
+  }
+  int finalize(float* ep_stats, float* time_outs, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize<real>, dim3(1), dim3(1024), 0, s, N, A.stat_sum, A.stat_cnt, ep_stats, timeout_now, time_outs, M.ep_len_s,
+                       counters_dev);
+    HIPCHK(hipGetLastError());
+    return 0;
+  }
+  int reset(const int32_t* ids, int n, int64_t* eplen, float* ep_stats, hipStream_t s) override {
+    HIPCHK(hipSetDevice(device));
+    if (!eplen) return fail("nm_reset: episode_length_dev is NULL");
+    const int32_t* idp = nullptr;
+    if (ids) {
+      if (n <= 0) return 0;  // reset_idx returns early on an empty id list (env.py:344)
+      for (int i = 0; i < n; i++)
+        if (ids[i] < 0 || ids[i] >= N) return fail("nm_reset: env id out of range");
+      HIPCHK(hipMemcpyAsync(ids_dev, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+      idp = ids_dev;
+    } else n = N;
+    nm::Args<real> a = A;
+    a.eplen = eplen;
+    a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
+    hipLaunchKernelGGL(k_reset<real>, dim3((n + 255) / 256), dim3(256), 0, s, M, a, idp, n);
+    HIPCHK(hipGetLastError());
+    return finalize(ep_stats, nullptr, s);
+  }
+  int step(const float* actions, int64_t* eplen, float* obs, float* rew, int64_t* done, float* time_outs, float* ep_stats, int physics_only,
+           hipStream_t s) override {
+    HIPCHK(hipSetDevice(device));
+    if (!actions) return fail("nm_step: actions_dev is NULL");
+    if (!physics_only && (!eplen || !obs || !rew || !done)) return fail("nm_step: NULL output pointer");
+    nm::Args<real> a = A;
+    a.actions = actions; a.eplen = eplen; a.obs = obs; a.rew = rew; a.done = done; a.timeout_now = timeout_now;
+    a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
+    a.physics_only = physics_only;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (prof_on) {  // HIP events on the launch stream around the dominant kernel only (bench.py's roofline leg)
+      if (prof_used == prof_ev.size()) {
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        prof_ev.push_back({e0, e1});
+      }
+      e0 = prof_ev[prof_used].first; e1 = prof_ev[prof_used].second;
+      prof_used++;
+      HIPCHK(hipEventRecord(e0, s));
+    }
+    hipLaunchKernelGGL(k_env_step<real>, dim3(N), dim3(64), 0, s, (const nm::Model<real>*)M_dev, a);
+    HIPCHK(hipGetLastError());
+    if (prof_on) HIPCHK(hipEventRecord(e1, s));
+    if (physics_only) return 0;
+    return finalize(ep_stats, time_outs, s);
+  }
+  int d2h(const real* dev, double* host, size_t n) {
+    if (!host) return 0;
+    std::vector<real> tmp(n);
+    HIPCHK(hipMemcpy(tmp.data(), dev, n * sizeof(real), hipMemcpyDeviceToHost));
+    for (size_t i = 0; i < n; i++) host[i] = (double)tmp[i];
+    return 0;
+  }
+  int h2d(real* dev, const double* host, size_t n) {
+    if (!host) return 0;
+    std::vector<real> tmp(n);
+    for (size_t i = 0; i < n; i++) tmp[i] = (real)host[i];
+    HIPCHK(hipMemcpy(dev, tmp.data(), n * sizeof(real), hipMemcpyHostToDevice));
+    return 0;
+  }
+  int get_state(double* qpos, double* qvel, double* qw) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return d2h(A.qpos, qpos, (size_t)N * 25) || d2h(A.qvel, qvel, (size_t)N * 24) || d2h(A.qwarm, qw, (size_t)N * 24);
+  }
+  int set_state(const double* qpos, const double* qvel, const double* qw) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return h2d(A.qpos, qpos, (size_t)N * 25) || h2d(A.qvel, qvel, (size_t)N * 24) || h2d(A.qwarm, qw, (size_t)N * 24);
+  }
+  int get_buffers(double* dp, double* dv, double* act, double* cmd, double* es) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return d2h(A.dofpos, dp, (size_t)N * 18) || d2h(A.dofvel, dv, (size_t)N * 18) || d2h(A.act, act, (size_t)N * 18) ||
+           d2h(A.cmd, cmd, (size_t)N * 3) || d2h(A.epsum, es, (size_t)N * 8);
+  }
+  int set_buffers(const double* dp, const double* dv, const double* act, const double* cmd, const double* es) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    return h2d(A.dofpos, dp, (size_t)N * 18) || h2d(A.dofvel, dv, (size_t)N * 18) || h2d(A.act, act, (size_t)N * 18) ||
+           h2d(A.cmd, cmd, (size_t)N * 3) || h2d(A.epsum, es, (size_t)N * 8);
+  }
+  int set_cmd_u(const double* u) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    cmd_u_on = u != nullptr;
+    return h2d(cmd_u_dev, u, (size_t)N * 4);
+  }
+  int counters(int64_t* out) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    long long c[2];
+    HIPCHK(hipMemcpy(c, counters_dev, sizeof c, hipMemcpyDeviceToHost));
+    out[0] = c[0]; out[1] = c[1];
+    return 0;
+  }
+  void set_dbg(void* p) override { A.dbg = (real*)p; }
+  int profiling(int on, double* sum_ms, int64_t* count) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    double sum = 0;
+    for (size_t i = 0; i < prof_used; i++) {
+      float ms = 0;
+      HIPCHK(hipEventElapsedTime(&ms, prof_ev[i].first, prof_ev[i].second));
+      sum += ms;
+    }
+    if (sum_ms) *sum_ms = sum;
+    if (count) *count = (int64_t)prof_used;
+    prof_used = 0;
+    prof_on = on != 0;
+    return 0;
+  }
+};
+
+// ------------------------------------------------------------------------------------------------ C ABI
+static const char* kRewardNames[NM_NUM_REWARDS] = {"action_rate", "body_contact_forces", "default_position", "dof_acc",
+                                                   "orientation", "tracking_ang_vel", "tracking_lin_vel", "termination"};
+extern "C" {
+const char* nm_last_error(void) { return g_err.c_str(); }
+int nm_policy_set_error(const char* m) { return fail(m); }
+const char* nm_reward_name(int i) { return (i >= 0 && i < NM_NUM_REWARDS) ? kRewardNames[i] : ""; }
+void nm_default_config(nm_config* c) {
+  nmhost::EnvConfig d;
+  c->decimation = d.decimation; c->p_gain = d.p_gain; c->action_scale = d.action_scale;
+  for (int i = 0; i < 3; i++) c->default_pos[i] = d.default_pos[i];
+  c->clip_actions = d.clip_actions; c->clip_observations = d.clip_observations;
+  c->obs_lin_vel = d.obs_lin_vel; c->obs_ang_vel = d.obs_ang_vel; c->obs_dof_pos = d.obs_dof_pos; c->obs_dof_vel = d.obs_dof_vel;
+  c->episode_length_s = d.episode_length_s; c->resampling_time = d.resampling_time;
+  c->max_lin_vel_x = d.max_lin_vel_x; c->max_ang_vel = d.max_ang_vel;
+  c->termination_contact_force = d.termination_contact_force; c->tracking_sigma = d.tracking_sigma;
+  for (int i = 0; i < NM_NUM_REWARDS; i++) c->reward_scales[i] = d.rew_scales[i];
+}
+int nm_create(const nm_config* cfg, int32_t num_envs, int32_t device, uint64_t seed, int64_t env_id_offset, int32_t dtype, nm_env** out) {
+  if (!out) return fail("nm_create: out is NULL");
+  *out = nullptr;
+  if (num_envs <= 0) return fail("nm_create: num_envs must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail("nm_create: no HIP device available (this backend has no CPU path)");
+  if (device < 0 || device >= ndev) return fail("nm_create: bad device index");
+  nmhost::EnvConfig c;
+  if (cfg) {
+    if (cfg->decimation < 1) return fail("nm_create: decimation must be >= 1");
+    c.decimation = cfg->decimation; c.p_gain = cfg->p_gain; c.action_scale = cfg->action_scale;
+    for (int i = 0; i < 3; i++) c.default_pos[i] = cfg->default_pos[i];
+    c.clip_actions = cfg->clip_actions; c.clip_observations = cfg->clip_observations;
+    c.obs_lin_vel = cfg->obs_lin_vel; c.obs_ang_vel = cfg->obs_ang_vel; c.obs_dof_pos = cfg->obs_dof_pos; c.obs_dof_vel = cfg->obs_dof_vel;
+    c.episode_length_s = cfg->episode_length_s; c.resampling_time = cfg->resampling_time;
+    c.max_lin_vel_x = cfg->max_lin_vel_x; c.max_ang_vel = cfg->max_ang_vel;
+    c.termination_contact_force = cfg->termination_contact_force; c.tracking_sigma = cfg->tracking_sigma;
+    for (int i = 0; i < NM_NUM_REWARDS; i++) c.rew_scales[i] = cfg->reward_scales[i];
+  }
+  nm_env* e;
+  int rc;
+  if (dtype == NM_DTYPE_F64) { auto* p = new Env<double>(); rc = p->init(c, num_envs, device, seed, env_id_offset); e = p; }
+  else if (dtype == NM_DTYPE_F32) { auto* p = new Env<float>(); rc = p->init(c, num_envs, device, seed, env_id_offset); e = p; }
+  else return fail("nm_create: dtype must be NM_DTYPE_F32 or NM_DTYPE_F64");
+  if (rc) { delete e; return 1; }
+  *out = e;
+  return 0;
+}
+int nm_destroy(nm_env* env) { delete env; return 0; }
+int32_t nm_num_envs(const nm_env* env) { return env ? env->N : 0; }
+int32_t nm_dtype(const nm_env* env) { return env ? env->dtype : -1; }
+#define NEED(e) if (!(e)) return fail("null nm_env")
+int nm_reset(nm_env* env, const int32_t* ids, int32_t n, int64_t* eplen, float* ep_stats, void* stream) {
+  NEED(env); return env->reset(ids, n, eplen, ep_stats, (hipStream_t)stream);
+}
+int nm_step(nm_env* env, const float* actions, int64_t* eplen, float* obs, float* rew, int64_t* done, float* time_outs, float* ep_stats,
+            void* stream) {
+  NEED(env); return env->step(actions, eplen, obs, rew, done, time_outs, ep_stats, 0, (hipStream_t)stream);
+}
+int nm_step_physics(nm_env* env, const float* actions, void* stream) {
+  NEED(env); return env->step(actions, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1, (hipStream_t)stream);
+}
+int nm_get_state(nm_env* env, double* qpos, double* qvel, double* qw) { NEED(env); return env->get_state(qpos, qvel, qw); }
+int nm_set_state(nm_env* env, const double* qpos, const double* qvel, const double* qw) { NEED(env); return env->set_state(qpos, qvel, qw); }
+int nm_get_buffers(nm_env* env, double* dp, double* dv, double* act, double* cmd, double* es) { NEED(env); return env->get_buffers(dp, dv, act, cmd, es); }
+int nm_set_buffers(nm_env* env, const double* dp, const double* dv, const double* act, const double* cmd, const double* es) {
+  NEED(env); return env->set_buffers(dp, dv, act, cmd, es);
+}
+int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_cmd_u(u); }
+int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
+int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
+int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count) { NEED(env); return env->profiling(enable, sum_ms, count); }
+}

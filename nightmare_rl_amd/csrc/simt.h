@@ -1,0 +1,186 @@
+// simt.h - the thin SIMT vocabulary the wave-per-env kernels are written in.
+//
+// Device build (hipcc, gfx950): V<T> is simply T (one value per lane of the 64-wide wavefront), masks are
+// bool, cross-lane ops are CDNA wave intrinsics (v_readlane, DPP/ds_bpermute butterflies, s_ballot).
+// Host build (-DNM_EMUL, used only by tests/emul): V<T> is an explicit 64-element vector and every
+// statement runs for all 64 lanes in lockstep, so the *same kernel source* can be checked against the CPU
+// oracle in a container without a GPU. The emulation is test scaffolding; the product library is device-only.
+//
+// Rules for kernel code written against this header:
+//   * no per-lane `if`: use sel(mask, a, b) and masked stores; uniform control flow only
+//   * masks combine with & | ! (never && ||)
+//   * literals are wrapped: real(0.5)
+#pragma once
+#include <stdint.h>
+
+#define NM_WAVE 64
+
+#ifndef NM_EMUL
+// =====================================================================================  DEVICE (gfx950)
+#include <hip/hip_runtime.h>
+#define NM_FN __device__ __forceinline__
+namespace simt {
+template <class T> using V = T;
+using VB = bool;
+
+NM_FN int lane_id() { return (int)threadIdx.x; }
+template <class T> NM_FN T sel(bool c, T a, T b) { return c ? a : b; }
+NM_FN float vsqrt(float x) { return sqrtf(x); }
+NM_FN double vsqrt(double x) { return sqrt(x); }
+NM_FN float vabs(float x) { return fabsf(x); }
+NM_FN double vabs(double x) { return fabs(x); }
+NM_FN float vmax(float a, float b) { return fmaxf(a, b); }
+NM_FN double vmax(double a, double b) { return fmax(a, b); }
+NM_FN float vmin(float a, float b) { return fminf(a, b); }
+NM_FN double vmin(double a, double b) { return fmin(a, b); }
+NM_FN int vmin(int a, int b) { return a < b ? a : b; }
+NM_FN int vmax(int a, int b) { return a > b ? a : b; }
+NM_FN void vsincos(float x, float* s, float* c) { sincosf(x, s, c); }
+NM_FN void vsincos(double x, double* s, double* c) { sincos(x, s, c); }
+NM_FN float vexp(float x) { return expf(x); }
+NM_FN double vexp(double x) { return exp(x); }
+NM_FN float vacos(float x) { return acosf(x); }
+NM_FN double vacos(double x) { return acos(x); }
+NM_FN float vpow(float x, float p) { return powf(x, p); }
+NM_FN double vpow(double x, double p) { return pow(x, p); }
+NM_FN bool visbad(float x) { return !(fabsf(x) <= 1e10f); }
+NM_FN bool visbad(double x) { return !(fabs(x) <= 1e10); }
+template <class T> NM_FN T to_real(int i) { return (T)i; }
+
+// value of lane l (l wave-uniform) as a wave-uniform scalar
+NM_FN int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
+NM_FN float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
+NM_FN double rdlane(double x, int l) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), l), hi = __builtin_amdgcn_readlane(__double2hiint(x), l);
+  return __hiloint2double(hi, lo);
+}
+// x with lane l (wave-uniform) replaced by the wave-uniform value v. The lane id goes through an empty asm so
+// the `lane == l` mask is recomputed here (v_cmp + v_cndmask) instead of being hoisted out of the solver's
+// iteration loops by LICM, where 64+ live masks (2 SGPRs each) spill the scalar register file.
+template <class T> NM_FN T wrlane(T x, T v, int l) {
+  int ln = (int)threadIdx.x;
+  asm volatile("" : "+v"(ln));
+  return ln == l ? v : x;
+}
+template <class T> NM_FN T uniform(T x) { return rdlane(x, 0); }
+NM_FN bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
+// value of lane (lane ^ m)
+template <class T> NM_FN T shfl_xor(T x, int m) { return __shfl_xor(x, m, 64); }
+// butterfly sum: every lane ends with the same, order-defined total
+template <class T> NM_FN T wsum(T x) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) x = x + __shfl_xor(x, m, 64);
+  return rdlane(x, 0);
+}
+NM_FN bool wany(bool c) { return __ballot(c) != 0ull; }
+NM_FN uint64_t ballot(bool c) { return __ballot(c); }
+// argmax with lowest-index tie break; returns uniform (value, index)
+template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    T ov = __shfl_xor(val, m, 64);
+    int oi = __shfl_xor(idx, m, 64);
+    bool take = (ov > val) | ((ov == val) & (oi < idx));
+    val = take ? ov : val;
+    idx = take ? oi : idx;
+  }
+  *best = rdlane(val, 0);
+  *ibest = rdlane(idx, 0);
+}
+template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
+template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; }
+template <class T> NM_FN T gldv(const T* p, int i) { return p[i]; }
+template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) p[i] = v; }
+NM_FN void wave_sync() { __syncthreads(); }
+}  // namespace simt
+
+#else
+// =====================================================================================  HOST EMULATION (tests only)
+#include <cmath>
+#include <cstring>
+#define NM_FN inline
+namespace simt {
+template <class T> struct V {
+  T v[NM_WAVE];
+  V() {}
+  V(T s) { for (int i = 0; i < NM_WAVE; i++) v[i] = s; }
+#define NM_BIN(op)                                                                                   \
+  friend V operator op(const V& a, const V& b) { V r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
+  NM_BIN(+) NM_BIN(-) NM_BIN(*) NM_BIN(/) NM_BIN(%) NM_BIN(&) NM_BIN(|) NM_BIN(>>) NM_BIN(<<)
+#undef NM_BIN
+#define NM_CMP(op)                                                                                      \
+  friend V<bool> operator op(const V& a, const V& b) { V<bool> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
+  NM_CMP(<) NM_CMP(>) NM_CMP(<=) NM_CMP(>=) NM_CMP(==) NM_CMP(!=)
+#undef NM_CMP
+  friend V operator-(const V& a) { V r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = -a.v[i]; return r; }
+  friend V operator!(const V& a) { V r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = !a.v[i]; return r; }
+  V& operator+=(const V& b) { for (int i = 0; i < NM_WAVE; i++) v[i] += b.v[i]; return *this; }
+  V& operator-=(const V& b) { for (int i = 0; i < NM_WAVE; i++) v[i] -= b.v[i]; return *this; }
+  V& operator*=(const V& b) { for (int i = 0; i < NM_WAVE; i++) v[i] *= b.v[i]; return *this; }
+};
+// float % is not defined: only instantiate % for ints (templates instantiate lazily per use, fine)
+using VB = V<bool>;
+
+NM_FN V<int> lane_id() { V<int> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = i; return r; }
+#define NM_SEL(T)                                                                                              \
+  NM_FN V<T> sel(const VB& c, const V<T>& a, const V<T>& b) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; } \
+  NM_FN T sel(bool c, T a, T b) { return c ? a : b; }
+NM_SEL(float) NM_SEL(double) NM_SEL(int)
+#undef NM_SEL
+#define NM_MAP1(name, expr)                                                                                   \
+  NM_FN V<float> name(const V<float>& a) { V<float> r; for (int i = 0; i < NM_WAVE; i++) { float x = a.v[i]; r.v[i] = expr; } return r; } \
+  NM_FN V<double> name(const V<double>& a) { V<double> r; for (int i = 0; i < NM_WAVE; i++) { double x = a.v[i]; r.v[i] = expr; } return r; } \
+  NM_FN float name(float x) { return expr; }                                                                  \
+  NM_FN double name(double x) { return expr; }
+NM_MAP1(vsqrt, std::sqrt(x)) NM_MAP1(vabs, std::fabs(x)) NM_MAP1(vexp, std::exp(x)) NM_MAP1(vacos, std::acos(x))
+#undef NM_MAP1
+#define NM_MAP2(name, expr, T)                                                                               \
+  NM_FN V<T> name(const V<T>& a, const V<T>& b) { V<T> r; for (int i = 0; i < NM_WAVE; i++) { T x = a.v[i], y = b.v[i]; r.v[i] = expr; } return r; } \
+  NM_FN T name(T x, T y) { return expr; }
+NM_MAP2(vmax, (x > y ? x : y), float) NM_MAP2(vmax, (x > y ? x : y), double) NM_MAP2(vmax, (x > y ? x : y), int)
+NM_MAP2(vmin, (x < y ? x : y), float) NM_MAP2(vmin, (x < y ? x : y), double) NM_MAP2(vmin, (x < y ? x : y), int)
+NM_MAP2(vpow, std::pow(x, y), float) NM_MAP2(vpow, std::pow(x, y), double)
+#undef NM_MAP2
+template <class T> NM_FN void vsincos(const V<T>& x, V<T>* s, V<T>* c) { for (int i = 0; i < NM_WAVE; i++) { s->v[i] = std::sin(x.v[i]); c->v[i] = std::cos(x.v[i]); } }
+NM_FN void vsincos(float x, float* s, float* c) { *s = std::sin(x); *c = std::cos(x); }
+NM_FN void vsincos(double x, double* s, double* c) { *s = std::sin(x); *c = std::cos(x); }
+template <class T> NM_FN VB visbad(const V<T>& a) { VB r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = !(std::fabs(a.v[i]) <= (T)1e10); return r; }
+NM_FN bool visbad(float x) { return !(std::fabs(x) <= 1e10f); }
+NM_FN bool visbad(double x) { return !(std::fabs(x) <= 1e10); }
+template <class T> NM_FN V<T> to_real(const V<int>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)a.v[i]; return r; }
+template <class T> NM_FN T to_real(int a) { return (T)a; }
+
+template <class T> NM_FN T rdlane(const V<T>& x, int l) { return x.v[l]; }
+template <class T> NM_FN T rdlane(T x, int) { return x; }
+template <class T> NM_FN V<T> wrlane(V<T> x, T v, int l) { x.v[l] = v; return x; }
+template <class T> NM_FN T uniform(const V<T>& x) { return x.v[0]; }
+template <class T> NM_FN T uniform(T x) { return x; }
+template <class T> NM_FN V<T> shfl_xor(const V<T>& x, int m) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[i ^ m]; return r; }
+template <class T> NM_FN T wsum(V<T> x) {
+  for (int m = 1; m < 64; m <<= 1) { V<T> o = shfl_xor(x, m); x = x + o; }
+  return x.v[0];
+}
+template <class T> NM_FN T wsum(T x) { for (int m = 1; m < 64; m <<= 1) x = x + x; return x; }
+NM_FN bool wany(const VB& c) { for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) return true; return false; }
+NM_FN uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) m |= 1ull << i; return m; }
+template <class T> NM_FN void wargmax(V<T> val, V<int> idx, T* best, int* ibest) {
+  for (int m = 1; m < 64; m <<= 1) {
+    V<T> ov = shfl_xor(val, m);
+    V<int> oi = shfl_xor(idx, m);
+    VB take = (ov > val) | ((ov == val) & (oi < idx));
+    val = sel(take, ov, val);
+    idx = sel(take, oi, idx);
+  }
+  *best = val.v[0];
+  *ibest = idx.v[0];
+}
+template <class T> NM_FN V<T> ldsv(const T* a, const V<int>& i) { V<T> r; for (int k = 0; k < NM_WAVE; k++) r.v[k] = a[i.v[k]]; return r; }
+template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
+template <class T> NM_FN void stsv(T* a, const V<int>& i, const V<T>& v, const VB& m) { for (int k = 0; k < NM_WAVE; k++) if (m.v[k]) a[i.v[k]] = v.v[k]; }
+template <class T> NM_FN void stsv(T* a, const V<int>& i, T v, const VB& m) { for (int k = 0; k < NM_WAVE; k++) if (m.v[k]) a[i.v[k]] = v; }
+template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p, i); }
+template <class T> NM_FN void gstv(T* p, const V<int>& i, const V<T>& v, const VB& m) { stsv(p, i, v, m); }
+template <class T> NM_FN void gstv(T* p, const V<int>& i, T v, const VB& m) { stsv(p, i, v, m); }
+NM_FN void wave_sync() {}
+}  // namespace simt
+#endif

@@ -1,0 +1,223 @@
+"""NightmareV3Env: the reference's vectorised env surface (reference envs/nightmare_v3_env.py:26-396) over the
+MI355X-native step kernel. Same constructor, attributes and return tuples; state lives in HBM and every call is
+asynchronous on the current torch stream.
+
+Differences a caller can observe (all documented in DESIGN.md):
+  * returned tensors are views of persistent device buffers, valid until the next step() (the reference returns
+    fresh CPU tensors, :311)
+  * commands come from a counter-based generator keyed by (seed, global env id) instead of numpy's global RNG (:327-330)
+  * no viewer / state recording (`cfg.viewer.*` must be False)
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .helpers import class_to_dict
+from .nightmare_v3_config import NightmareV3Config
+
+
+class NightmareV3Env:
+    def __init__(self, cfg: NightmareV3Config, log_dir="/tmp/nightmare_v3/logs", num_threads=1, *, device=None, seed=0,
+                 env_id_offset=0, dtype=torch.float32):
+        self.cfg = cfg
+        self.log_dir = log_dir
+        self.thread_num = num_threads  # accepted for API parity; the GPU path has no host threads
+        self.num_envs = int(cfg.env.num_envs)
+        self.num_obs = int(cfg.env.num_obs)
+        self.num_privileged_obs = self.num_obs  # reference :34
+        self.num_actions = int(cfg.env.num_actions)
+        if self.num_obs != _lib.NUM_OBS or self.num_actions != _lib.NUM_ACTIONS:
+            raise ValueError("the compiled path is specialised for num_obs=66, num_actions=18")
+        if cfg.viewer.render or cfg.viewer.record_states:
+            raise ValueError("cfg.viewer.render / record_states are not available on the GPU path (set them to False)")
+        if cfg.noise.add_noise:
+            raise NotImplementedError("observation noise (reference :304-305) is not on the compiled path yet")
+        if cfg.env.tibia_contact_mode != 1 or cfg.env.body_contact_mode != 1:
+            raise NotImplementedError("only tibia/body_contact_mode == 1 (the reference default) is compiled")
+        if not torch.cuda.is_available():
+            raise _lib.NightmareHipError("NightmareV3Env needs a HIP device: there is no CPU path")
+        L = _lib.load()
+        self._L = L
+        dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+        if dev.type != "cuda":
+            raise _lib.NightmareHipError(f"device must be a HIP device, got {dev}")
+        self.device = dev if dev.index is not None else torch.device("cuda", torch.cuda.current_device())
+        self.num_dof = 18
+        self.gravity_vec = np.array([0., 0., -9.81])
+        self.reward_scales = class_to_dict(cfg.rewards.scales)
+        self.command_ranges = cfg.commands.ranges
+        self.obs_scales = cfg.normalization.obs_scales
+        # timestep 0.008 (reference models/nightmare_v3/mjmodel.xml:3) x decimation
+        self.dt = 0.008 * cfg.control.decimation
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        self.default_dof_pos = np.array(cfg.control.default_pos, dtype=np.float64)
+        # reward table: zero scales dropped, the rest x dt (reference :123-128); names with no compiled function are rejected
+        names = _lib.reward_names()
+        for key in list(self.reward_scales.keys()):
+            if self.reward_scales[key] == 0:
+                self.reward_scales.pop(key)
+            else:
+                if key not in names:
+                    raise NotImplementedError(f"reward '{key}' has a non-zero scale but is not on the compiled path ({names})")
+                self.reward_scales[key] *= self.dt
+        self.reward_names = [n for n in self.reward_scales if n != "termination"]
+        dp = list(cfg.control.default_pos)
+        if any(abs(dp[i] - dp[i % 3]) > 0 for i in range(18)):
+            raise NotImplementedError("default_pos must repeat per leg (coxa, femur, tibia)")
+        c = _lib.NmConfig()
+        L.nm_default_config(C.byref(c))
+        c.decimation = int(cfg.control.decimation)
+        c.p_gain = float(cfg.control.p_gain)
+        c.action_scale = float(cfg.control.action_scale)
+        for i in range(3):
+            c.default_pos[i] = float(dp[i])
+        c.clip_actions = float(cfg.normalization.clip_actions)
+        c.clip_observations = float(cfg.normalization.clip_observations)
+        c.obs_lin_vel, c.obs_ang_vel = float(self.obs_scales.lin_vel), float(self.obs_scales.ang_vel)
+        c.obs_dof_pos, c.obs_dof_vel = float(self.obs_scales.dof_pos), float(self.obs_scales.dof_vel)
+        c.episode_length_s = float(cfg.env.episode_length_s)
+        c.resampling_time = float(cfg.commands.resampling_time)
+        c.max_lin_vel_x, c.max_ang_vel = float(self.command_ranges.max_lin_vel_x), float(self.command_ranges.max_ang_vel)
+        c.termination_contact_force = float(cfg.env.termination_contact_force)
+        c.tracking_sigma = float(cfg.rewards.tracking_sigma)
+        raw = class_to_dict(cfg.rewards.scales)
+        for i, n in enumerate(names):
+            c.reward_scales[i] = float(raw.get(n, 0.0))
+        self._dtype = _lib.DTYPE_F64 if dtype == torch.float64 else _lib.DTYPE_F32
+        h = C.c_void_p()
+        _lib.check(L.nm_create(C.byref(c), self.num_envs, self.device.index or 0, int(seed), int(env_id_offset), self._dtype, C.byref(h)))
+        self._h = h
+        N, dev = self.num_envs, self.device
+        self.obs_buf = torch.zeros((N, self.num_obs), dtype=torch.float32, device=dev)
+        self.privileged_obs_buf = None
+        self.rew_buf = torch.zeros(N, dtype=torch.float32, device=dev)
+        self.reset_buf = torch.ones(N, dtype=torch.int64, device=dev)
+        self.episode_length_buf = torch.zeros(N, dtype=torch.int64, device=dev)  # assignable, like the reference (:88)
+        self.time_out_buf = torch.zeros(N, dtype=torch.float32, device=dev)
+        self._ep_stats = torch.zeros(_lib.NUM_REWARDS, dtype=torch.float32, device=dev)
+        self._stat_names = names
+        self.extras = {}
+        self.common_step_counter = 0
+
+    # ------------------------------------------------------------------ reference surface
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _eplen(self):
+        b = self.episode_length_buf
+        if b.device != self.device or b.dtype != torch.int64 or not b.is_contiguous():
+            b = b.to(device=self.device, dtype=torch.int64).contiguous()
+            self.episode_length_buf = b
+        return b
+
+    def _fill_extras(self):
+        # reference :363-371: one 0-d float32 tensor per reward + time_outs; views of buffers the kernel refreshes
+        self.extras["episode"] = {"rew_" + n: self._ep_stats[i] for i, n in enumerate(self._stat_names)}
+        if self.cfg.env.send_timeouts:
+            self.extras["time_outs"] = self.time_out_buf
+
+    def step(self, actions):
+        a = actions.to(device=self.device, dtype=torch.float32)
+        if a.dim() != 2 or a.shape[0] != self.num_envs or a.shape[1] < 18:
+            raise ValueError(f"actions must be [{self.num_envs}, 18], got {tuple(a.shape)}")
+        a = a[:, :18].contiguous()
+        ep = self._eplen()
+        _lib.check(self._L.nm_step(self._h, a.data_ptr(), ep.data_ptr(), self.obs_buf.data_ptr(), self.rew_buf.data_ptr(),
+                                   self.reset_buf.data_ptr(), self.time_out_buf.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
+        self._last_actions = a  # keep the input alive until the kernel has read it
+        self.common_step_counter += 1
+        if "episode" not in self.extras:
+            self._fill_extras()
+        return self.obs_buf, None, self.rew_buf, self.reset_buf, self.extras
+
+    def step_physics(self, actions):
+        """mj_step x decimation only (no rewards/obs/reset): the 'dynamics+contact kernel' configuration."""
+        a = actions.to(device=self.device, dtype=torch.float32)[:, :18].contiguous()
+        _lib.check(self._L.nm_step_physics(self._h, a.data_ptr(), self._stream()))
+        self._last_actions = a
+
+    def reset_idx(self, env_ids):
+        if env_ids is None:
+            ids, n = None, 0
+        else:
+            idsa = np.ascontiguousarray(torch.as_tensor(env_ids).detach().cpu().numpy().astype(np.int32))
+            if idsa.size == 0:
+                return
+            ids, n = idsa.ctypes.data_as(C.c_void_p), int(idsa.size)
+        ep = self._eplen()
+        _lib.check(self._L.nm_reset(self._h, ids, n, ep.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
+        self._fill_extras()
+
+    def reset(self):
+        self.reset_idx(None)
+        obs, priv, _, _, _ = self.step(torch.zeros((self.num_envs, self.num_actions), device=self.device))
+        return obs, priv
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return None
+
+    def render(self):
+        pass
+
+    # ------------------------------------------------------------------ state access (parity tests, checkpoints)
+    def get_state(self):
+        N = self.num_envs
+        qpos, qvel, qw = np.empty((N, 25)), np.empty((N, 24)), np.empty((N, 24))
+        _lib.check(self._L.nm_get_state(self._h, qpos.ctypes.data, qvel.ctypes.data, qw.ctypes.data))
+        return qpos, qvel, qw
+
+    def set_state(self, qpos=None, qvel=None, qacc_warmstart=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (qpos, qvel, qacc_warmstart)]
+        _lib.check(self._L.nm_set_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+
+    def get_buffers(self):
+        N = self.num_envs
+        out = dict(dof_pos=np.empty((N, 18)), dof_vel=np.empty((N, 18)), actions=np.empty((N, 18)), commands=np.empty((N, 3)),
+                   episode_sums=np.empty((N, 8)))
+        _lib.check(self._L.nm_get_buffers(self._h, *[out[k].ctypes.data for k in ("dof_pos", "dof_vel", "actions", "commands", "episode_sums")]))
+        return out
+
+    def set_buffers(self, dof_pos=None, dof_vel=None, actions=None, commands=None, episode_sums=None):
+        arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (dof_pos, dof_vel, actions, commands, episode_sums)]
+        _lib.check(self._L.nm_set_buffers(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+
+    def set_command_uniforms(self, u):
+        a = None if u is None else np.ascontiguousarray(u, np.float64).reshape(self.num_envs, 4)
+        _lib.check(self._L.nm_set_command_uniforms(self._h, None if a is None else a.ctypes.data))
+
+    def counters(self):
+        out = np.zeros(2, np.int64)
+        _lib.check(self._L.nm_get_counters(self._h, out.ctypes.data))
+        return dict(contacts_dropped=int(out[0]), bad_state_resets=int(out[1]))
+
+    def set_debug_buffer(self, t):
+        self._dbg = t
+        _lib.check(self._L.nm_set_debug_buffer(self._h, None if t is None else t.data_ptr()))
+
+    def profile(self, enable):
+        """(sum_ms, count) of step-kernel HIP-event times since the last call; sets event recording on/off."""
+        ms, cnt = C.c_double(0), C.c_int64(0)
+        _lib.check(self._L.nm_profile(self._h, int(bool(enable)), C.byref(ms), C.byref(cnt)))
+        return ms.value, cnt.value
+
+    @property
+    def commands(self):
+        return self.get_buffers()["commands"]
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            torch.cuda.synchronize(self.device)
+            self._L.nm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,88 @@
+// nm_emul.cpp - TEST SCAFFOLDING: compiles the device kernel source (nightmare_rl_amd/csrc/nm_core.h) for the
+// host with -DNM_EMUL, where simt.h executes the 64 lanes of a wavefront in lockstep. Lets the exact device
+// algorithm (lane mappings, LDS traffic, cross-lane reductions, solver sweeps) be checked against the CPU oracle
+// in a container without a GPU. Never linked into the product library; the product has no CPU path.
+#define NM_EMUL 1
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../nightmare_rl_amd/csrc/nm_host_model.h"
+
+namespace {
+struct EmuBase {
+  virtual ~EmuBase() {}
+  virtual void step(const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done, float* to, int nsub, int physics_only,
+                    double* dbg, double* stat_sum, int* stat_cnt) = 0;
+  virtual void get(int what, double* out) = 0;
+  virtual void set(int what, const double* in) = 0;
+  virtual int64_t* eplen() = 0;
+};
+
+template <class real> struct Emu : EmuBase {
+  int N;
+  nmhost::Tables<real> T;
+  nm::Model<real> M;
+  std::vector<real> qpos, qvel, qwarm, dofpos, dofvel, act, cmd, epsum;
+  std::vector<int64_t> ep;
+  std::vector<uint32_t> ctr;
+  uint64_t seed;
+  int64_t off;
+  Emu(int n, uint64_t s, int64_t o) : N(n), seed(s), off(o) {
+    T.build();
+    nmhost::EnvConfig cfg;
+    T.fill_scalars(M, cfg);
+    M.legc = T.legc.data(); M.basec = T.basec.data(); M.colc = T.colc.data(); M.hullv = T.hullv.data();
+    M.hullnbr = T.hullnbr.data(); M.footc = T.footc.data(); M.qpos0 = T.qpos0.data();
+    qpos.assign((size_t)N * 25, 0); qvel.assign((size_t)N * 24, 0); qwarm.assign((size_t)N * 24, 0);
+    dofpos.assign((size_t)N * 18, 0); dofvel.assign((size_t)N * 18, 0); act.assign((size_t)N * 18, 0);
+    cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * 8, 0); ep.assign(N, 0); ctr.assign(N, 0);
+    for (int i = 0; i < N; i++)
+      for (int j = 0; j < 25; j++) qpos[(size_t)i * 25 + j] = T.qpos0[j];
+  }
+  std::vector<real>* arr(int what) {
+    switch (what) {
+      case 0: return &qpos; case 1: return &qvel; case 2: return &qwarm; case 3: return &dofpos; case 4: return &dofvel;
+      case 5: return &act; case 6: return &cmd; case 7: return &epsum;
+    }
+    return nullptr;
+  }
+  void get(int what, double* out) override { auto* a = arr(what); for (size_t i = 0; i < a->size(); i++) out[i] = (double)(*a)[i]; }
+  void set(int what, const double* in) override { auto* a = arr(what); for (size_t i = 0; i < a->size(); i++) (*a)[i] = (real)in[i]; }
+  int64_t* eplen() override { return ep.data(); }
+  void step(const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done, float* to, int nsub, int physics_only,
+            double* dbg, double* stat_sum, int* stat_cnt) override {
+    std::vector<real> cu, dbgr((size_t)N * nm::kDbgN, 0), ssum(8, 0);
+    if (cmd_u) { cu.resize((size_t)N * 4); for (size_t i = 0; i < cu.size(); i++) cu[i] = (real)cmd_u[i]; }
+    int scnt[4] = {0, 0, 0, 0};
+    nm::Args<real> A;
+    A.N = N; A.seed = seed; A.env_offset = off;
+    A.qpos = qpos.data(); A.qvel = qvel.data(); A.qwarm = qwarm.data(); A.dofpos = dofpos.data(); A.dofvel = dofvel.data();
+    A.act = act.data(); A.cmd = cmd.data(); A.epsum = epsum.data(); A.eplen = ep.data(); A.rngctr = ctr.data();
+    A.actions = actions; A.cmd_u = cmd_u ? cu.data() : nullptr;
+    A.obs = obs; A.rew = rew; A.timeout_now = to; A.done = done; A.stat_sum = ssum.data(); A.stat_cnt = scnt;
+    A.dbg = dbg ? dbgr.data() : nullptr; A.nsub = nsub; A.physics_only = physics_only;
+    static thread_local nm::Sh<real> sh;
+    for (int e = 0; e < N; e++) nm::env_step(sh, M, A, e);
+    if (dbg) for (size_t i = 0; i < dbgr.size(); i++) dbg[i] = (double)dbgr[i];
+    if (stat_sum) for (int k = 0; k < 8; k++) stat_sum[k] = (double)ssum[k];
+    if (stat_cnt) { stat_cnt[0] = scnt[0]; stat_cnt[1] = scnt[1]; }
+  }
+};
+}  // namespace
+
+extern "C" {
+void* emu_create(int N, int use_double, uint64_t seed, int64_t env_off) {
+  if (use_double) return new Emu<double>(N, seed, env_off);
+  return new Emu<float>(N, seed, env_off);
+}
+void emu_destroy(void* h) { delete (EmuBase*)h; }
+void emu_step(void* h, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done, float* to, int nsub, int physics_only,
+              double* dbg, double* stat_sum, int* stat_cnt) {
+  ((EmuBase*)h)->step(actions, cmd_u, obs, rew, done, to, nsub, physics_only, dbg, stat_sum, stat_cnt);
+}
+void emu_get(void* h, int what, double* out) { ((EmuBase*)h)->get(what, out); }
+void emu_set(void* h, int what, const double* in) { ((EmuBase*)h)->set(what, in); }
+int64_t* emu_eplen(void* h) { return ((EmuBase*)h)->eplen(); }
+int emu_dbg_n() { return nm::kDbgN; }
+}

@@ -1,0 +1,92 @@
+"""The DEVICE kernel source (nightmare_rl_amd/csrc/nm_core.h) compiled for the host as a 64-lane lockstep SIMT
+emulation (tests/emul) and checked against the reference-generated goldens. This is what can be verified about
+the HIP path in a container without a GPU; the `-m gpu` tests repeat it on the real kernel through the C ABI."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz"]
+
+
+def teacher_forced(make_env, g, steps=None):
+    """Load the golden pre-step state each step, step once, return per-env max |obs error|, |rew error| and flags."""
+    N, T = g["actions"].shape[1], g["actions"].shape[0] if steps is None else steps
+    e = make_env(N)
+    qpos, qvel, qw = g["init_qpos"], g["init_qvel"], g["init_qacc_warmstart"]
+    dofpos, dofvel, cmd, ep = g["init_dof_pos"], g["init_dof_vel"], g["init_commands"], g["init_ep_len"]
+    act = np.zeros((N, 18))
+    oerr, rerr, flags, state = [], [], 0, []
+    for t in range(T):
+        e.set("qpos", qpos); e.set("qvel", qvel); e.set("qwarm", qw); e.set("dofpos", dofpos); e.set("dofvel", dofvel)
+        e.set("cmd", cmd); e.set("act", act)
+        e.eplen[:] = ep
+        obs, rew, done, to = e.step(g["actions"][t], cmd_u=g["cmd_u"][t])
+        oerr.append(np.abs(obs.astype(np.float64) - g["obs"][t]).max(axis=1))
+        rerr.append(np.abs(rew.astype(np.float64) - g["rew"][t]))
+        flags += int((done != g["done"][t]).sum()) + int((to != g["time_outs"][t]).sum())
+        state.append(max(np.abs(e.get("qpos") - g["qpos"][t]).max(), np.abs(e.get("qvel") - g["qvel"][t]).max()))
+        np.testing.assert_array_equal(e.eplen, g["ep_len"][t])
+        qpos, qvel, qw = g["qpos"][t], g["qvel"][t], g["qacc_warmstart"][t]
+        dofpos, dofvel, cmd, ep = g["dof_pos"][t], g["dof_vel"][t], g["commands"][t], g["ep_len"][t]
+        act = np.clip(g["actions"][t].astype(np.float32) * np.float32(0.2), -1, 1).astype(np.float64)
+    return np.concatenate(oerr), np.concatenate(rerr), flags, max(state)
+
+
+@pytest.fixture(scope="module")
+def emul():
+    from emul import emul as em
+    em.build()
+    return em
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_fp64_device_algorithm_is_exact(emul, name):
+    g = load_golden(name)
+    oerr, rerr, flags, serr = teacher_forced(lambda N: emul.EmulEnv(N, double=True), g)
+    assert flags == 0
+    assert oerr.max() <= 1e-7 and rerr.max() <= 2e-7   # float32 rounding of the returned tensors only
+    assert serr < 1e-9
+
+
+@pytest.mark.parametrize("name", SCENARIOS)
+def test_fp32_device_algorithm_within_tolerance(emul, name):
+    """Stated tolerance (BASELINE north_star): obs/reward within 1e-4 of the reference path, teacher-forced single step.
+    A support-vertex tie on a flat foot (two hull vertices within ~1e-8 m of the same depth) flips the discrete arg-max
+    between precisions and is the one allowed kind of outlier; its frequency is bounded here."""
+    g = load_golden(name)
+    oerr, rerr, flags, _ = teacher_forced(lambda N: emul.EmulEnv(N, double=False), g)
+    assert flags == 0
+    n_out = int((oerr > 1e-4).sum())
+    assert n_out <= max(1, len(oerr) // 500), (n_out, len(oerr))
+    assert np.percentile(oerr, 99) < 2e-5 and np.median(oerr) < 2e-6
+    assert np.percentile(rerr, 99) < 2e-5
+
+
+def test_free_run_tracks_oracle(emul, oracle_mod):
+    """Free-running fp32 device code vs the fp64 oracle from reset, same actions, internal counter RNG on both sides."""
+    N, T = 8, 25
+    rng = np.random.default_rng(5)
+    e = emul.EmulEnv(N, double=False, seed=7)
+    o = oracle_mod.OracleEnv(N, seed=7)
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, 18)).astype(np.float32)
+        obs, rew, done, to = e.step(a)
+        oobs, orew, odone, oto = o.step(a)
+        np.testing.assert_array_equal(done, odone)
+        np.testing.assert_allclose(obs, oobs, atol=5e-4)   # airborne + first contact: errors still at rounding level
+        np.testing.assert_allclose(rew, orew, atol=5e-4)
+
+
+def test_counter_rng_matches_oracle(emul, oracle_mod):
+    """Command resampling draws: device code and oracle share the (seed, global env id, counter) generator."""
+    N = 5
+    e = emul.EmulEnv(N, double=True, seed=123, env_off=40)
+    o = oracle_mod.OracleEnv(N, seed=123, env_id_offset=40)
+    e.eplen[:] = 624
+    o.set_buffers(ep_len=np.full(N, 624))
+    a = np.zeros((N, 18), np.float32)
+    e.step(a)
+    o.step(a)
+    np.testing.assert_allclose(e.get("cmd"), o.get_buffers()["commands"], atol=1e-15)
+    assert np.abs(e.get("cmd")).sum() > 0
