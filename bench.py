@@ -26,10 +26,22 @@ B_DYN = 656    # dynamics-only (config 2)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
+def host_cores():
+    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box gives a share of a big host)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return max(1, min(n, 16)) if n > 64 else n   # no quota visible on a >64-thread host: stay within the documented 16-CPU share
+
+
 def cpu_baseline(seconds_budget=15.0):
     """The CPU oracle (a port: MuJoCo itself is not installable) on this box's host cores, bounded sample."""
     from oracle import oracle as orc
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = host_cores()
     n = 1024
     env = orc.OracleEnv(n, seed=0, num_threads=cores)
     env.reset()
@@ -79,6 +91,7 @@ def main():
     from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config
     from nightmare_rl_amd.envs.nightmare_v3_env import NightmareV3Env
     from nightmare_rl_amd.policy import ActorMLP
+    from nightmare_rl_amd.distributed import gather_returns
 
     E = args.envs_per_gpu
     cfg = NightmareV3Config()
@@ -94,11 +107,11 @@ def main():
     horizon = 80
 
     def one_step(i):
-        nonlocal returns
+        nonlocal returns, gathered
         _, _, rew, done, _ = env.step(acts[i % pool])
         returns += rew
         if (i + 1) % horizon == 0 and world > 1:     # PPO-update boundary: one all-gather of per-env returns over xGMI
-            dist.all_gather_into_tensor(gathered, returns)
+            gathered = gather_returns(returns, total_envs=world * E)
             returns.zero_()
 
     def sync():

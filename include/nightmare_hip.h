@@ -95,6 +95,9 @@ int nm_set_debug_buffer(nm_env* env, void* dbg_dev);
  * kernel with HIP events on the launch stream. Each call synchronises, returns the summed kernel time and the
  * launch count since the previous call, clears them, and sets the new enable state. */
 int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count);
+/* Measurement only (results become wrong): skip kernel stages to attribute time. bit0 collision, bit1 solver sweeps,
+ * bit2 whole constraint stage, bit3 smooth-dynamics stage. 0 = normal. */
+int nm_set_ablation(nm_env* env, int32_t mask);
 
 /* ActorCritic.act mean path (rsl_rl v1.0.2 ActorCritic: Linear->ELU x n_hidden -> Linear), batched over envs
  * on the MFMA units. weights: device f32, layer l is [out_l, in_l] row-major followed by bias [out_l]

@@ -83,6 +83,7 @@ template <class real> struct Args {
   real* dbg;             // optional [N][kDbgN]
   int nsub;              // decimation
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
+  int ablate;            // measurement only: bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage
 };
 constexpr int kDbgN = 256;
 
@@ -584,7 +585,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
 
 // =========================================================================================  stage C
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
-template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last) {
+template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep = false) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const int ncon = uniform(sh.ncon), nefc = 4 * ncon;
@@ -742,7 +743,7 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
   stsv(sh.dbg_b, lane, bb, lane < kMaxRow); stsv(sh.dbg_a, lane, ARjj, lane < kMaxRow); stsv(sh.dbg_f0, lane, f, lane < kMaxRow);
 #endif
   // ---- mj_solPGS: Gauss-Seidel over rows; every lane keeps its residual current by a rank-1 update
-  for (int iter = 0; iter < M.pgs_iters; iter++) {
+  for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
     real improvement = real(0);
 #pragma unroll
     for (int i = 0; i < kMaxRow; i++) {
@@ -764,7 +765,7 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
     if (improvement * M.pgs_scale < M.pgs_tol) break;
   }
   // ---- mj_solNoSlip: per opposing pyramid pair, exact 1-D minimisation along (f0 - f1) without R
-  for (int iter = 0; iter < M.noslip_iters; iter++) {
+  for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
     real improvement = real(0);
     if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
 #pragma unroll
@@ -935,7 +936,7 @@ template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) 
 }
 
 // mj_step(model, data, 1)
-template <class real> NM_FN void substep(Sh<real>& sh, const Model<real>& M, bool last, int* dropped) {
+template <class real> NM_FN void substep(Sh<real>& sh, const Model<real>& M, bool last, int* dropped, int ablate) {
   const V<int> lane = lane_id();
   {  // mj_checkPos / mj_checkVel
     VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
@@ -950,9 +951,10 @@ template <class real> NM_FN void substep(Sh<real>& sh, const Model<real>& M, boo
     wave_sync();
   }
   for (int attempt = 0; attempt < 2; attempt++) {
-    stage_smooth(sh, M, last);
-    stage_collide(sh, M, dropped);
-    stage_constraint(sh, M, last);
+    if (!(ablate & 8)) stage_smooth(sh, M, last);
+    if (!(ablate & 1)) stage_collide(sh, M, dropped); else { sh.ncon = 0; wave_sync(); }
+    if (ablate & 4) { sh.ncon = 0; wave_sync(); }
+    stage_constraint(sh, M, last, (ablate & 2) != 0);
     bool bad = stage_integrate(sh, M);
     if (!bad) break;
     sh.nwarn += 1;  // mj_checkAcc: reset, run the forward pass again, integrate
@@ -997,7 +999,7 @@ template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, co
   wave_sync();
   // ---- E2 (env.py:200): mj_step(model, data, decimation)
   int dropped = 0;
-  for (int s = 0; s < A.nsub; s++) substep(sh, M, s == A.nsub - 1, &dropped);
+  for (int s = 0; s < A.nsub; s++) substep(sh, M, s == A.nsub - 1, &dropped, A.ablate);
   // ---- store physics state
   gstv(A.qpos, lane + env * kNQ, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
   gstv(A.qvel, lane + env * kNV, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);

@@ -97,6 +97,7 @@ struct nm_env {
   virtual int counters(int64_t* out) = 0;
   virtual void set_dbg(void* p) = 0;
   virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
+  virtual void set_ablate(int m) = 0;
 };
 
 template <class real> struct Env : nm_env {
@@ -256,6 +257,7 @@ template <class real> struct Env : nm_env {
     return 0;
   }
   void set_dbg(void* p) override { A.dbg = (real*)p; }
+  void set_ablate(int m) override { A.ablate = m; }
   int profiling(int on, double* sum_ms, int64_t* count) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipDeviceSynchronize());
@@ -343,5 +345,6 @@ int nm_set_buffers(nm_env* env, const double* dp, const double* dv, const double
 int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_cmd_u(u); }
 int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
+int nm_set_ablation(nm_env* env, int32_t mask) { NEED(env); env->set_ablate(mask); return 0; }
 int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count) { NEED(env); return env->profiling(enable, sum_ms, count); }
 }

@@ -1,0 +1,43 @@
+"""Multi-GPU layout of the env batch: contiguous shards by global env id, one process per GPU, and the single
+collective the path has - an all-gather of per-env episode returns at PPO-update boundaries (RCCL over xGMI on
+GPUs; gloo on CPU tensors in tests). The rollout itself needs no communication."""
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total_envs, rank, world_size):
+    """Global env ids [lo, hi) owned by `rank`: contiguous blocks, remainder spread over the first ranks."""
+    base, rem = divmod(int(total_envs), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_returns(local_returns, total_envs=None):
+    """All ranks get the per-env returns of every env, ordered by global env id. One collective call."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return local_returns.clone()
+    world = dist.get_world_size()
+    n = torch.tensor([local_returns.numel()], device=local_returns.device)
+    sizes = [torch.zeros_like(n) for _ in range(world)]
+    if total_envs is not None:
+        counts = [shard_range(total_envs, r, world)[1] - shard_range(total_envs, r, world)[0] for r in range(world)]
+    else:
+        dist.all_gather(sizes, n)
+        counts = [int(s.item()) for s in sizes]
+    if len(set(counts)) == 1:
+        out = torch.empty(sum(counts), dtype=local_returns.dtype, device=local_returns.device)
+        dist.all_gather_into_tensor(out, local_returns.contiguous())
+        return out
+    parts = [torch.empty(c, dtype=local_returns.dtype, device=local_returns.device) for c in counts]
+    dist.all_gather(parts, local_returns.contiguous())
+    return torch.cat(parts)
+
+
+def global_advantage_stats(adv):
+    """Mean / std of advantages over ALL ranks (rsl_rl normalises over envs x steps): one 3-float all-reduce."""
+    s = torch.stack([adv.sum(), (adv * adv).sum(), torch.tensor(float(adv.numel()), device=adv.device, dtype=adv.dtype)])
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(s)
+    mean = s[0] / s[2]
+    var = (s[1] / s[2] - mean * mean).clamp_min(0) * (s[2] / (s[2] - 1).clamp_min(1))
+    return mean, var.sqrt()
