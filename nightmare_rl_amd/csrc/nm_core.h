@@ -100,6 +100,7 @@ template <class real> struct Sh {
   int cleg[kMaxCon];
   real jrow[kMaxRow * kJRow];
   real sens[16], cvb[6];
+  real legtmp[kNLEG * 66];        // per-leg staging between the forward and backward chain passes: 3 x (S6 I10 f6)
   real efc_f[kMaxRow];
 #ifdef NM_DEBUG_SOLVER
   real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
@@ -243,195 +244,226 @@ NM_FN uint32_t rand_u24_bits(uint64_t seed, uint64_t genv, uint32_t ctr) {
 
 // =========================================================================================  stage A
 // Everything "smooth": kinematics, inertia blocks + both factorisations, bias, servo forces, qacc_smooth.
+// Forward pass down each leg chain (one leg per lane) parks per-link results in the leg's LDS slots; the
+// backward pass picks them up again. That keeps the live register set small enough for 4 waves/SIMD.
+constexpr int kLinkTmp = 22;  // per link in LDS: S(6) I10(10) f(6)
+
+template <class real> NM_FN real legsum(const V<real>& x, const VB& isleg) {  // sum over the six leg lanes -> uniform
+  return wsum8<real>(sel(isleg, x, V<real>(real(0))));
+}
+
 template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M, bool last) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const V<int> leg = lane % 6;
   const VB isleg = lane < 6;
+  const V<int> slot = leg * (3 * kLinkTmp);
 
   // ---- base frame (uniform)
-  real qw = sh.qpos[3], qx = sh.qpos[4], qy = sh.qpos[5], qz = sh.qpos[6];
   real Rb[9];
   {
+    real qw = sh.qpos[3], qx = sh.qpos[4], qy = sh.qpos[5], qz = sh.qpos[6];
     real q00 = qw * qw, q01 = qw * qx, q02 = qw * qy, q03 = qw * qz, q11 = qx * qx, q12 = qx * qy, q13 = qx * qz, q22 = qy * qy,
          q23 = qy * qz, q33 = qz * qz;
     Rb[0] = q00 + q11 - q22 - q33; Rb[4] = q00 - q11 + q22 - q33; Rb[8] = q00 - q11 - q22 + q33;
     Rb[1] = real(2) * (q12 - q03); Rb[2] = real(2) * (q13 + q02); Rb[3] = real(2) * (q12 + q03);
     Rb[5] = real(2) * (q23 - q01); Rb[6] = real(2) * (q13 - q02); Rb[7] = real(2) * (q23 + q01);
   }
-  real vb[6];  // base spatial velocity about its origin: [w_world; v_origin]
+  real vb[6], ab[6];  // base spatial velocity [w_world; v_origin] and bias acceleration (-gravity + v x w)
   {
     real wl[3] = {sh.qvel[3], sh.qvel[4], sh.qvel[5]};
     matvec3(vb, Rb, wl);
     vb[3] = sh.qvel[0]; vb[4] = sh.qvel[1]; vb[5] = sh.qvel[2];
-  }
-  real ab[6];  // base bias acceleration: -gravity + v x w  (cdof_dot of the free joint's rotational dofs)
-  {
     real t[3];
     cross3(t, vb + 3, vb);
     ab[0] = ab[1] = ab[2] = real(0);
     ab[3] = t[0]; ab[4] = t[1]; ab[5] = t[2] + M.grav;
   }
-  // base body spatial inertia about its own origin
-  real Ib10[10], bcom[3];
-  {
-    real ipos[3] = {M.basec[0], M.basec[1], M.basec[2]}, Ibody[6] = {M.basec[3], M.basec[4], M.basec[5], M.basec[6], M.basec[7], M.basec[8]};
-    real d[3];
-    matvec3(d, Rb, ipos);
-    spatial_inertia(Ib10, Rb, Ibody, d, M.basec[9], real(0));
-    bcom[0] = M.basec[9] * d[0]; bcom[1] = M.basec[9] * d[1]; bcom[2] = M.basec[9] * d[2];  // mass-weighted, legs added below
-  }
-
-  // ---- leg chains, one leg per lane
-  vr Rp[9], pp[3];
-#pragma unroll
-  for (int k = 0; k < 9; k++) Rp[k] = vr(Rb[k]);
-  pp[0] = pp[1] = pp[2] = vr(real(0));
-  vr S[3][6], I10[3][10], vk[3][6], fk[3][6];
-  vr vpar[6], apar[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) { vpar[k] = vr(vb[k]); apar[k] = vr(ab[k]); }
-  vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    const V<int> cb = leg * kLegN + k * kLinkN;
-    vr c[kLinkN];
-#pragma unroll
-    for (int j = 0; j < kLinkN; j++) c[j] = gldv(M.legc, cb + j);
-    vr q = ldsv(sh.qpos, leg * 3 + (7 + k)), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
-    vr pos[3], t3[3], R0[9], aw[3];
-    matvec3(t3, Rp, c + 0);
-    pos[0] = pp[0] + t3[0]; pos[1] = pp[1] + t3[1]; pos[2] = pp[2] + t3[2];
-    matmul3(R0, Rp, c + 3);
-    matvec3(aw, R0, c + 12);
-    vr s, co;
-    vsincos(q, &s, &co);
-    vr Rl[9];  // Rodrigues about the local axis
-    {
-      const vr* a = c + 12;
-      vr oc = vr(real(1)) - co;
-      Rl[0] = co + oc * a[0] * a[0]; Rl[1] = oc * a[0] * a[1] - s * a[2]; Rl[2] = oc * a[0] * a[2] + s * a[1];
-      Rl[3] = oc * a[0] * a[1] + s * a[2]; Rl[4] = co + oc * a[1] * a[1]; Rl[5] = oc * a[1] * a[2] - s * a[0];
-      Rl[6] = oc * a[0] * a[2] - s * a[1]; Rl[7] = oc * a[1] * a[2] + s * a[0]; Rl[8] = co + oc * a[2] * a[2];
-    }
-    vr R[9];
-    matmul3(R, R0, Rl);
-    vr d[3];
-    matvec3(t3, R, c + 15);
-    d[0] = pos[0] + t3[0]; d[1] = pos[1] + t3[1]; d[2] = pos[2] + t3[2];
-    spatial_inertia(I10[k], R, c + 18, d, c[24], real(0));
-    mcom[0] += c[24] * d[0]; mcom[1] += c[24] * d[1]; mcom[2] += c[24] * d[2];
-    // motion vector about the base origin: [a; r x a]
-    S[k][0] = aw[0]; S[k][1] = aw[1]; S[k][2] = aw[2];
-    cross3(S[k] + 3, pos, aw);
-    // publish joint anchor/axis (row stage) and, for the tibia, the collision frame
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      stsv(sh.anc, leg * 9 + (3 * k + j), pos[j], isleg);
-      stsv(sh.axs, leg * 9 + (3 * k + j), aw[j], isleg);
-    }
-    if (k == 2) {
-#pragma unroll
-      for (int j = 0; j < 9; j++) stsv(sh.colR, (leg + 1) * 9 + j, R[j], isleg);
-#pragma unroll
-      for (int j = 0; j < 3; j++) stsv(sh.colp, (leg + 1) * 3 + j, pos[j], isleg);
-    }
-    // RNE forward: velocity, bias acceleration, body force
-    vr Sd[6], a[6], t6[6], u6[6];
-    cross_motion(Sd, vpar, S[k]);
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      vk[k][j] = vpar[j] + S[k][j] * qd;
-      a[j] = apar[j] + Sd[j] * qd;
-    }
-    inert_mul(t6, I10[k], a);
-    inert_mul(u6, I10[k], vk[k]);
-    cross_force(fk[k], vk[k], u6);
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      fk[k][j] = fk[k][j] + t6[j];
-      vpar[j] = vk[k][j];
-      apar[j] = a[j];
-    }
-#pragma unroll
-    for (int j = 0; j < 9; j++) Rp[j] = R[j];
-    pp[0] = pos[0]; pp[1] = pos[1]; pp[2] = pos[2];
-  }
-  // base collision frame + base rotation for the row stage
 #pragma unroll
   for (int j = 0; j < 9; j++) { sh.colR[j] = Rb[j]; sh.Rb[j] = Rb[j]; }
   sh.colp[0] = sh.colp[1] = sh.colp[2] = real(0);
 #pragma unroll
   for (int j = 0; j < 6; j++) sh.wv[j] = vb[j];
-  if (last) {  // subtree COM (relative to the base origin) -> cvel[1] as MuJoCo reports it (about the COM)
-    real cr[3];
-#pragma unroll
-    for (int j = 0; j < 3; j++) cr[j] = (bcom[j] + lanesum6<real>(mcom[j])) / M.total_mass;
-    real t[3];
-    cross3(t, vb, cr);
-    sh.cvb[0] = vb[0]; sh.cvb[1] = vb[1]; sh.cvb[2] = vb[2];
-    sh.cvb[3] = vb[3] + t[0]; sh.cvb[4] = vb[4] + t[1]; sh.cvb[5] = vb[5] + t[2];
-  }
 
-  // ---- RNE backward + generalized bias
-#pragma unroll
-  for (int j = 0; j < 6; j++) { fk[1][j] += fk[2][j]; }
-#pragma unroll
-  for (int j = 0; j < 6; j++) { fk[0][j] += fk[1][j]; }
-  vr cl[3];
-#pragma unroll
-  for (int k = 0; k < 3; k++) cl[k] = dot6<vr>(S[k], fk[k]);
-  real fb[6];
+  // ---- forward pass down the chain: pose, motion vector, spatial inertia, velocity, bias acceleration, body force
+  vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
   {
-    real t6[6], u6[6], w6[6];
+    vr Rp[9], pp[3], vpar[6], apar[6];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rp[k] = vr(Rb[k]);
+    pp[0] = pp[1] = pp[2] = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < 6; k++) { vpar[k] = vr(vb[k]); apar[k] = vr(ab[k]); }
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const V<int> cb = leg * kLegN + k * kLinkN;
+      vr q = ldsv(sh.qpos, leg * 3 + (7 + k)), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
+      vr pos[3], t3[3], aw[3], R[9];
+      {
+        vr bpos[3] = {gldv(M.legc, cb), gldv(M.legc, cb + 1), gldv(M.legc, cb + 2)};
+        matvec3(t3, Rp, bpos);
+        pos[0] = pp[0] + t3[0]; pos[1] = pp[1] + t3[1]; pos[2] = pp[2] + t3[2];
+      }
+      {
+        vr ax[3] = {gldv(M.legc, cb + 12), gldv(M.legc, cb + 13), gldv(M.legc, cb + 14)};
+        vr R0[9];
+        {
+          vr bR[9];
+#pragma unroll
+          for (int j = 0; j < 9; j++) bR[j] = gldv(M.legc, cb + 3 + j);
+          matmul3(R0, Rp, bR);
+        }
+        matvec3(aw, R0, ax);
+        vr s, co;
+        vsincos(q, &s, &co);
+        vr oc = vr(real(1)) - co;
+        vr Rl[9];  // Rodrigues about the local axis
+        Rl[0] = co + oc * ax[0] * ax[0]; Rl[1] = oc * ax[0] * ax[1] - s * ax[2]; Rl[2] = oc * ax[0] * ax[2] + s * ax[1];
+        Rl[3] = oc * ax[0] * ax[1] + s * ax[2]; Rl[4] = co + oc * ax[1] * ax[1]; Rl[5] = oc * ax[1] * ax[2] - s * ax[0];
+        Rl[6] = oc * ax[0] * ax[2] - s * ax[1]; Rl[7] = oc * ax[1] * ax[2] + s * ax[0]; Rl[8] = co + oc * ax[2] * ax[2];
+        matmul3(R, R0, Rl);
+      }
+      // publish joint anchor/axis (row stage) and, for the tibia, the collision frame
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        stsv(sh.anc, leg * 9 + (3 * k + j), pos[j], isleg);
+        stsv(sh.axs, leg * 9 + (3 * k + j), aw[j], isleg);
+      }
+      if (k == 2) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) stsv(sh.colR, (leg + 1) * 9 + j, R[j], isleg);
+#pragma unroll
+        for (int j = 0; j < 3; j++) stsv(sh.colp, (leg + 1) * 3 + j, pos[j], isleg);
+      }
+      vr S[6], I10[10];
+      S[0] = aw[0]; S[1] = aw[1]; S[2] = aw[2];
+      cross3(S + 3, pos, aw);  // motion vector about the base origin: [a; r x a]
+      {
+        vr ipos[3] = {gldv(M.legc, cb + 15), gldv(M.legc, cb + 16), gldv(M.legc, cb + 17)};
+        vr Ib[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) Ib[j] = gldv(M.legc, cb + 18 + j);
+        vr mass = gldv(M.legc, cb + 24);
+        vr d[3];
+        matvec3(t3, R, ipos);
+        d[0] = pos[0] + t3[0]; d[1] = pos[1] + t3[1]; d[2] = pos[2] + t3[2];
+        spatial_inertia(I10, R, Ib, d, mass, real(0));
+        mcom[0] += mass * d[0]; mcom[1] += mass * d[1]; mcom[2] += mass * d[2];
+      }
+      // RNE forward: velocity, bias acceleration, body force
+      vr f[6];
+      {
+        vr Sd[6], t6[6], u6[6];
+        cross_motion(Sd, vpar, S);
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+          vpar[j] = vpar[j] + S[j] * qd;
+          apar[j] = apar[j] + Sd[j] * qd;
+        }
+        inert_mul(t6, I10, apar);
+        inert_mul(u6, I10, vpar);
+        cross_force(f, vpar, u6);
+#pragma unroll
+        for (int j = 0; j < 6; j++) f[j] = f[j] + t6[j];
+      }
+      const V<int> o = slot + k * kLinkTmp;
+#pragma unroll
+      for (int j = 0; j < 6; j++) stsv(sh.legtmp, o + j, S[j], isleg);
+#pragma unroll
+      for (int j = 0; j < 10; j++) stsv(sh.legtmp, o + (6 + j), I10[j], isleg);
+#pragma unroll
+      for (int j = 0; j < 6; j++) stsv(sh.legtmp, o + (16 + j), f[j], isleg);
+#pragma unroll
+      for (int j = 0; j < 9; j++) Rp[j] = R[j];
+      pp[0] = pos[0]; pp[1] = pos[1]; pp[2] = pos[2];
+    }
+  }
+  wave_sync();
+
+  // ---- backward pass: accumulated body forces -> bias; composite inertias -> M_l, Mlb
+  vr Ml[6], Mlb[3][6], cl[3], fs[6], Ic[10];
+#pragma unroll
+  for (int j = 0; j < 6; j++) fs[j] = vr(real(0));
+#pragma unroll
+  for (int j = 0; j < 10; j++) Ic[j] = vr(real(0));
+#pragma unroll
+  for (int k = 2; k >= 0; k--) {
+    const V<int> o = slot + k * kLinkTmp;
+    vr S[6], F[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) S[j] = ldsv(sh.legtmp, o + j);
+#pragma unroll
+    for (int j = 0; j < 10; j++) Ic[j] += ldsv(sh.legtmp, o + (6 + j));
+#pragma unroll
+    for (int j = 0; j < 6; j++) fs[j] += ldsv(sh.legtmp, o + (16 + j));
+    cl[k] = dot6<vr>(S, fs);
+    inert_mul(F, Ic, S);
+    Mlb[k][0] = F[3]; Mlb[k][1] = F[4]; Mlb[k][2] = F[5];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Mlb[k][3 + j] = F[0] * Rb[j] + F[1] * Rb[3 + j] + F[2] * Rb[6 + j];
+    const int dk = (k == 0) ? 0 : (k == 1 ? 3 : 5);  // packed index of M[k][k] in (00 01 02 11 12 22)
+    Ml[dk] = dot6<vr>(S, F);
+#pragma unroll
+    for (int jj = 0; jj < k; jj++) {  // ancestors within the leg
+      vr Sj[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) Sj[j] = ldsv(sh.legtmp, slot + (jj * kLinkTmp + j));
+      Ml[(jj == 0) ? k : 4] = dot6<vr>(Sj, F);  // (0,k) -> index k ; (1,2) -> index 4
+    }
+  }
+  // ---- base: own inertia/force + legs
+  real Icb[10], cbias[6];
+  {
+    real Ib10[10];
+    real ipos[3] = {M.basec[0], M.basec[1], M.basec[2]}, Ibody[6] = {M.basec[3], M.basec[4], M.basec[5], M.basec[6], M.basec[7], M.basec[8]};
+    real d[3];
+    matvec3(d, Rb, ipos);
+    spatial_inertia(Ib10, Rb, Ibody, d, M.basec[9], real(0));
+    if (last) {  // subtree COM (relative to the base origin) -> cvel[1] as MuJoCo reports it (about the COM)
+      real cr[3], t[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) cr[j] = (M.basec[9] * d[j] + legsum<real>(mcom[j], isleg)) / M.total_mass;
+      cross3(t, vb, cr);
+      sh.cvb[0] = vb[0]; sh.cvb[1] = vb[1]; sh.cvb[2] = vb[2];
+      sh.cvb[3] = vb[3] + t[0]; sh.cvb[4] = vb[4] + t[1]; sh.cvb[5] = vb[5] + t[2];
+    }
+    real fb[6], t6[6], u6[6], w6[6];
     inert_mul(t6, Ib10, ab);
     inert_mul(u6, Ib10, vb);
     cross_force(w6, vb, u6);
 #pragma unroll
-    for (int j = 0; j < 6; j++) fb[j] = t6[j] + w6[j] + lanesum6<real>(fk[0][j]);
+    for (int j = 0; j < 6; j++) fb[j] = t6[j] + w6[j] + legsum<real>(fs[j], isleg);
+    cbias[0] = fb[3]; cbias[1] = fb[4]; cbias[2] = fb[5];
+#pragma unroll
+    for (int j = 0; j < 3; j++) cbias[3 + j] = Rb[j] * fb[0] + Rb[3 + j] * fb[1] + Rb[6 + j] * fb[2];
+#pragma unroll
+    for (int j = 0; j < 10; j++) Icb[j] = Ib10[j] + legsum<real>(Ic[j], isleg);
   }
-  real cbias[6];
-  cbias[0] = fb[3]; cbias[1] = fb[4]; cbias[2] = fb[5];
-#pragma unroll
-  for (int j = 0; j < 3; j++) cbias[3 + j] = Rb[j] * fb[0] + Rb[3 + j] * fb[1] + Rb[6 + j] * fb[2];
-
-  // ---- composite inertias and the inertia blocks
-#pragma unroll
-  for (int j = 0; j < 10; j++) { I10[1][j] += I10[2][j]; }
-#pragma unroll
-  for (int j = 0; j < 10; j++) { I10[0][j] += I10[1][j]; }
-  real Icb[10];
-#pragma unroll
-  for (int j = 0; j < 10; j++) Icb[j] = Ib10[j] + lanesum6<real>(I10[0][j]);
-  vr F[3][6];
-#pragma unroll
-  for (int k = 0; k < 3; k++) inert_mul(F[k], I10[k], S[k]);
-  vr Ml[6];  // 00 01 02 11 12 22 (0 = coxa)
-  Ml[0] = dot6<vr>(S[0], F[0]); Ml[1] = dot6<vr>(S[0], F[1]); Ml[2] = dot6<vr>(S[0], F[2]);
-  Ml[3] = dot6<vr>(S[1], F[1]); Ml[4] = dot6<vr>(S[1], F[2]); Ml[5] = dot6<vr>(S[2], F[2]);
-  vr Mlb[3][6];
-#pragma unroll
-  for (int k = 0; k < 3; k++) {
-    Mlb[k][0] = F[k][3]; Mlb[k][1] = F[k][4]; Mlb[k][2] = F[k][5];
-#pragma unroll
-    for (int j = 0; j < 3; j++) Mlb[k][3 + j] = F[k][0] * Rb[j] + F[k][1] * Rb[3 + j] + F[k][2] * Rb[6 + j];
-  }
+  // base block of M from the composite inertia (I6, h = m*d, m) about the base origin, dofs (x y z | body axes a_j = Rb[:,j]):
+  //   trans-trans m*1 ; trans-rot column j = a_j x h ; rot-rot Rb' I Rb
   real Mbb[36];
   {
-    real Sb[6][6], Fb[6][6];
+#pragma unroll
+    for (int i = 0; i < 36; i++) Mbb[i] = real(0);
+    Mbb[0] = Mbb[7] = Mbb[14] = Icb[9];
+    real T[9];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
+      real a[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, c[3];
+      cross3(c, a, Icb + 6);
 #pragma unroll
-      for (int k = 0; k < 6; k++) { Sb[j][k] = real(0); Sb[3 + j][k] = real(0); }
-      Sb[j][3 + j] = real(1);
-      Sb[3 + j][0] = Rb[j]; Sb[3 + j][1] = Rb[3 + j]; Sb[3 + j][2] = Rb[6 + j];
+      for (int i = 0; i < 3; i++) { Mbb[6 * i + 3 + j] = c[i]; Mbb[6 * (3 + j) + i] = c[i]; }
+      T[j] = Icb[0] * a[0] + Icb[3] * a[1] + Icb[4] * a[2];       // (I a_j), stored column-wise: T[3*r + j]
+      T[3 + j] = Icb[3] * a[0] + Icb[1] * a[1] + Icb[5] * a[2];
+      T[6 + j] = Icb[4] * a[0] + Icb[5] * a[1] + Icb[2] * a[2];
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) inert_mul(Fb[j], Icb, Sb[j]);
+    for (int i = 0; i < 3; i++)
 #pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = 0; j < 6; j++) Mbb[6 * i + j] = dot6<real>(Sb[i], Fb[j]);
+      for (int j = i; j < 3; j++) {
+        real v = Rb[i] * T[j] + Rb[3 + i] * T[3 + j] + Rb[6 + i] * T[6 + j];
+        Mbb[6 * (3 + i) + 3 + j] = v; Mbb[6 * (3 + j) + 3 + i] = v;
+      }
   }
 
   // ---- block factorisations: M (pass 0) and M + h*kv*I on the actuated dofs (pass 1, implicitfast)
@@ -448,17 +480,6 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
       ldl3_solve(r3, Mi, col);
       W[0][j] = r3[0]; W[1][j] = r3[1]; W[2][j] = r3[2];
     }
-    real Sc[36];
-#pragma unroll
-    for (int i = 0; i < 6; i++)
-#pragma unroll
-      for (int j = i; j < 6; j++) {
-        vr cij = Mlb[0][i] * W[0][j] + Mlb[1][i] * W[1][j] + Mlb[2][i] * W[2][j];
-        real s = Mbb[6 * i + j] - lanesum6<real>(cij);
-        Sc[6 * i + j] = s; Sc[6 * j + i] = s;
-      }
-    real L[15], Di[6];
-    ldl6(Sc, L, Di);
     real* shMinv = pass ? sh.MinvH : sh.Minv;
     real* shW = pass ? sh.WH : sh.W;
     real* shL = pass ? sh.LbH : sh.Lb;
@@ -469,6 +490,17 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
     for (int k = 0; k < 3; k++)
 #pragma unroll
       for (int j = 0; j < 6; j++) stsv(shW, leg * 18 + (6 * k + j), W[k][j], isleg);
+    real Sc[36];
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i; j < 6; j++) {
+        vr cij = Mlb[0][i] * W[0][j] + Mlb[1][i] * W[1][j] + Mlb[2][i] * W[2][j];
+        real sc = Mbb[6 * i + j] - legsum<real>(cij, isleg);
+        Sc[6 * i + j] = sc; Sc[6 * j + i] = sc;
+      }
+    real L[15], Di[6];
+    ldl6(Sc, L, Di);
 #pragma unroll
     for (int j = 0; j < 15; j++) shL[j] = L[j];
 #pragma unroll
@@ -488,7 +520,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
 #pragma unroll
       for (int j = 0; j < 6; j++) {
         vr wy = W[0][j] * y[0] + W[1][j] * y[1] + W[2][j] * y[2];
-        xb[j] = -cbias[j] - lanesum6<real>(wy);
+        xb[j] = -cbias[j] - legsum<real>(wy, isleg);
         sh.qfs[j] = -cbias[j];
       }
       ldl6_solve(L, Di, xb);
@@ -807,8 +839,8 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
     for (int k = 0; k < 3; k++) sh.qfc[6 + 3 * l + k] = wsum<real>(sel(L == l, Jl[k] * f, vr(real(0))));
   // ---- touch sensors (only the last forward pass is observable after mj_step)
   if (last) {
-    vr nf = f + shfl_xor(f, 1);
-    nf = nf + shfl_xor(nf, 2);  // contact normal force = sum of its 4 pyramid edge forces
+    vr nf = f + shfl_xor1(f);
+    nf = nf + shfl_xor2(nf);  // contact normal force = sum of its 4 pyramid edge forces
     VB head = act & ((lane & 3) == 0) & (nf > vr(real(0)));
     // foot site sphere: ray from the contact point along -normal must hit it
     vr ft[3], fr;
@@ -867,7 +899,7 @@ template <class real> NM_FN bool stage_integrate(Sh<real>& sh, const Model<real>
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       vr wy = ldsv(shW, leg * 18 + j) * y[0] + ldsv(shW, leg * 18 + (6 + j)) * y[1] + ldsv(shW, leg * 18 + (12 + j)) * y[2];
-      xb[j] = sh.qfc[j] + (pass ? sh.qfs[j] : real(0)) - lanesum6<real>(wy);
+      xb[j] = sh.qfc[j] + (pass ? sh.qfs[j] : real(0)) - legsum<real>(wy, isleg);
     }
     ldl6_solve(shL, shD, xb);
 #pragma unroll

@@ -64,28 +64,58 @@ template <class T> NM_FN T wrlane(T x, T v, int l) {
 }
 template <class T> NM_FN T uniform(T x) { return rdlane(x, 0); }
 NM_FN bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
-// value of lane (lane ^ m)
-template <class T> NM_FN T shfl_xor(T x, int m) { return __shfl_xor(x, m, 64); }
-// butterfly sum: every lane ends with the same, order-defined total
-template <class T> NM_FN T wsum(T x) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) x = x + __shfl_xor(x, m, 64);
+// ---- DPP lane permutations inside a row of 16 lanes (no LDS traffic, ~VALU latency)
+#define NM_DPP_QUAD_XOR1 0xB1     /* quad_perm [1,0,3,2] */
+#define NM_DPP_QUAD_XOR2 0x4E     /* quad_perm [2,3,0,1] */
+#define NM_DPP_HALF_MIRROR 0x141  /* lane i <-> 7-i inside each 8 */
+#define NM_DPP_ROW_MIRROR 0x140   /* lane i <-> 15-i inside each 16 */
+template <int CTRL> NM_FN int dpp(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
+template <int CTRL> NM_FN float dpp(float x) { return __int_as_float(dpp<CTRL>(__float_as_int(x))); }
+template <int CTRL> NM_FN double dpp(double x) { return __hiloint2double(dpp<CTRL>(__double2hiint(x)), dpp<CTRL>(__double2loint(x))); }
+// value of lane (lane ^ 1) / (lane ^ 2)
+template <class T> NM_FN T shfl_xor1(T x) { return dpp<NM_DPP_QUAD_XOR1>(x); }
+template <class T> NM_FN T shfl_xor2(T x) { return dpp<NM_DPP_QUAD_XOR2>(x); }
+// sum of lanes 0..7 (wave-uniform): pairs, quads, then the two quads of the first 8
+template <class T> NM_FN T wsum8(T x) {
+  x = x + dpp<NM_DPP_QUAD_XOR1>(x);
+  x = x + dpp<NM_DPP_QUAD_XOR2>(x);
+  x = x + dpp<NM_DPP_HALF_MIRROR>(x);
   return rdlane(x, 0);
+}
+// sum of all 64 lanes (wave-uniform); fixed association order: 2,4,8,16 inside rows, then (r0+r1)+(r2+r3)
+template <class T> NM_FN T wsum(T x) {
+  x = x + dpp<NM_DPP_QUAD_XOR1>(x);
+  x = x + dpp<NM_DPP_QUAD_XOR2>(x);
+  x = x + dpp<NM_DPP_HALF_MIRROR>(x);
+  x = x + dpp<NM_DPP_ROW_MIRROR>(x);
+  return (rdlane(x, 0) + rdlane(x, 16)) + (rdlane(x, 32) + rdlane(x, 48));
 }
 NM_FN bool wany(bool c) { return __ballot(c) != 0ull; }
 NM_FN uint64_t ballot(bool c) { return __ballot(c); }
 // argmax with lowest-index tie break; returns uniform (value, index)
 template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) {
-    T ov = __shfl_xor(val, m, 64);
-    int oi = __shfl_xor(idx, m, 64);
-    bool take = (ov > val) | ((ov == val) & (oi < idx));
-    val = take ? ov : val;
-    idx = take ? oi : idx;
+#define NM_AM_STEP(CTRL)                                                   \
+  {                                                                        \
+    T ov = dpp<CTRL>(val);                                                 \
+    int oi = dpp<CTRL>(idx);                                               \
+    bool take = (ov > val) | ((ov == val) & (oi < idx));                   \
+    val = take ? ov : val;                                                 \
+    idx = take ? oi : idx;                                                 \
   }
-  *best = rdlane(val, 0);
-  *ibest = rdlane(idx, 0);
+  NM_AM_STEP(NM_DPP_QUAD_XOR1) NM_AM_STEP(NM_DPP_QUAD_XOR2) NM_AM_STEP(NM_DPP_HALF_MIRROR) NM_AM_STEP(NM_DPP_ROW_MIRROR)
+#undef NM_AM_STEP
+  T bv = rdlane(val, 0);
+  int bi = rdlane(idx, 0);
+#pragma unroll
+  for (int r = 16; r < 64; r += 16) {
+    T ov = rdlane(val, r);
+    int oi = rdlane(idx, r);
+    bool take = (ov > bv) | ((ov == bv) & (oi < bi));
+    bv = take ? ov : bv;
+    bi = take ? oi : bi;
+  }
+  *best = bv;
+  *ibest = bi;
 }
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; }
@@ -156,23 +186,25 @@ template <class T> NM_FN V<T> wrlane(V<T> x, T v, int l) { x.v[l] = v; return x;
 template <class T> NM_FN T uniform(const V<T>& x) { return x.v[0]; }
 template <class T> NM_FN T uniform(T x) { return x; }
 template <class T> NM_FN V<T> shfl_xor(const V<T>& x, int m) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[i ^ m]; return r; }
-template <class T> NM_FN T wsum(V<T> x) {
-  for (int m = 1; m < 64; m <<= 1) { V<T> o = shfl_xor(x, m); x = x + o; }
+template <class T> NM_FN V<T> shfl_xor1(const V<T>& x) { return shfl_xor(x, 1); }
+template <class T> NM_FN V<T> shfl_xor2(const V<T>& x) { return shfl_xor(x, 2); }
+template <class T> NM_FN V<T> half_mirror(const V<T>& x) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[(i & ~7) | (7 - (i & 7))]; return r; }
+template <class T> NM_FN V<T> row_mirror(const V<T>& x) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[(i & ~15) | (15 - (i & 15))]; return r; }
+template <class T> NM_FN T wsum8(V<T> x) {
+  x = x + shfl_xor(x, 1); x = x + shfl_xor(x, 2); x = x + half_mirror(x);
   return x.v[0];
 }
-template <class T> NM_FN T wsum(T x) { for (int m = 1; m < 64; m <<= 1) x = x + x; return x; }
+template <class T> NM_FN T wsum(V<T> x) {
+  x = x + shfl_xor(x, 1); x = x + shfl_xor(x, 2); x = x + half_mirror(x); x = x + row_mirror(x);
+  return (x.v[0] + x.v[16]) + (x.v[32] + x.v[48]);
+}
 NM_FN bool wany(const VB& c) { for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) return true; return false; }
 NM_FN uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) m |= 1ull << i; return m; }
 template <class T> NM_FN void wargmax(V<T> val, V<int> idx, T* best, int* ibest) {
-  for (int m = 1; m < 64; m <<= 1) {
-    V<T> ov = shfl_xor(val, m);
-    V<int> oi = shfl_xor(idx, m);
-    VB take = (ov > val) | ((ov == val) & (oi < idx));
-    val = sel(take, ov, val);
-    idx = sel(take, oi, idx);
-  }
-  *best = val.v[0];
-  *ibest = idx.v[0];
+  T bv = val.v[0]; int bi = idx.v[0];
+  for (int i = 1; i < NM_WAVE; i++)
+    if (val.v[i] > bv || (val.v[i] == bv && idx.v[i] < bi)) { bv = val.v[i]; bi = idx.v[i]; }
+  *best = bv; *ibest = bi;
 }
 template <class T> NM_FN V<T> ldsv(const T* a, const V<int>& i) { V<T> r; for (int k = 0; k < NM_WAVE; k++) r.v[k] = a[i.v[k]]; return r; }
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }

@@ -1,0 +1,17 @@
+"""Kernel-time microbench of the step kernel (HIP events), for A/B-ing builds on a GPU box."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config
+from nightmare_rl_amd.envs.nightmare_v3_env import NightmareV3Env
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+cfg = NightmareV3Config(); cfg.env.num_envs = N
+acts = (torch.rand(16, N, 18, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda()
+env = NightmareV3Env(cfg, seed=0); env.reset()
+for i in range(300): env.step(acts[i % 16])
+res = []
+for rep in range(3):
+    env.profile(True)
+    for i in range(200): env.step(acts[i % 16])
+    ms, n = env.profile(False)
+    res.append(ms / n * 1e3)
+print(f"N={N} step kernel avg us: " + " ".join(f"{r:.1f}" for r in res) + f"  -> {N / min(res):.2f} M env-steps/s (kernel only)")
