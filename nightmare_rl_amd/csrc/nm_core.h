@@ -100,6 +100,7 @@ template <class real> struct Sh {
   int cleg[kMaxCon];
   real jrow[kMaxRow * kJRow];
   real sens[16], cvb[6];
+  real mbb[36], sc[36];           // base block of M and its Schur complement (upper triangles)
   real legtmp[kNLEG * 66];        // per-leg staging between the forward and backward chain passes: 3 x (S6 I10 f6)
   real efc_f[kMaxRow];
 #ifdef NM_DEBUG_SOLVER
@@ -191,7 +192,7 @@ template <class X, class Y> NM_FN void ldl3_solve(X* x, const X* f, const Y* y) 
   x[2] = y2 * f[3] - f[0] * x1 - f[1] * x0;
   x[1] = x1; x[0] = x0;
 }
-// LDL' of a symmetric 6x6 given as full row-major S[36] (uniform): L strictly lower (15, row-major packed), Dinv(6)
+// LDL' of a symmetric 6x6 given by its upper triangle in row-major S[36] (wave-uniform, may live in LDS): L strictly lower (15, row-major packed), Dinv(6)
 template <class real> NM_FN void ldl6(const real* S, real* L, real* Dinv) {
   real Lf[36], D[6];
 #pragma unroll
@@ -204,7 +205,7 @@ template <class real> NM_FN void ldl6(const real* S, real* L, real* Dinv) {
     Dinv[j] = di;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
-      real s = S[6 * i + j];
+      real s = S[6 * j + i];  // upper triangle only
 #pragma unroll
       for (int k = 0; k < j; k++) s = s - Lf[6 * i + k] * Lf[6 * j + k] * D[k];
       Lf[6 * i + j] = s * di;
@@ -296,6 +297,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
     for (int k = 0; k < 6; k++) { vpar[k] = vr(vb[k]); apar[k] = vr(ab[k]); }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
+      sched_fence();
       const V<int> cb = leg * kLegN + k * kLinkN;
       vr q = ldsv(sh.qpos, leg * 3 + (7 + k)), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
       vr pos[3], t3[3], aw[3], R[9];
@@ -335,6 +337,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
 #pragma unroll
         for (int j = 0; j < 3; j++) stsv(sh.colp, (leg + 1) * 3 + j, pos[j], isleg);
       }
+      sched_fence();
       vr S[6], I10[10];
       S[0] = aw[0]; S[1] = aw[1]; S[2] = aw[2];
       cross3(S + 3, pos, aw);  // motion vector about the base origin: [a; r x a]
@@ -388,6 +391,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
   for (int j = 0; j < 10; j++) Ic[j] = vr(real(0));
 #pragma unroll
   for (int k = 2; k >= 0; k--) {
+    sched_fence();
     const V<int> o = slot + k * kLinkTmp;
     vr S[6], F[6];
 #pragma unroll
@@ -411,6 +415,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
       Ml[(jj == 0) ? k : 4] = dot6<vr>(Sj, F);  // (0,k) -> index k ; (1,2) -> index 4
     }
   }
+  sched_fence();
   // ---- base: own inertia/force + legs
   real Icb[10], cbias[6];
   {
@@ -441,8 +446,8 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
   }
   // base block of M from the composite inertia (I6, h = m*d, m) about the base origin, dofs (x y z | body axes a_j = Rb[:,j]):
   //   trans-trans m*1 ; trans-rot column j = a_j x h ; rot-rot Rb' I Rb
-  real Mbb[36];
-  {
+  {  // written to LDS (wave-uniform values do not deserve 36 VGPRs across both factorisation passes)
+    real* Mbb = sh.mbb;
 #pragma unroll
     for (int i = 0; i < 36; i++) Mbb[i] = real(0);
     Mbb[0] = Mbb[7] = Mbb[14] = Icb[9];
@@ -452,7 +457,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
       real a[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, c[3];
       cross3(c, a, Icb + 6);
 #pragma unroll
-      for (int i = 0; i < 3; i++) { Mbb[6 * i + 3 + j] = c[i]; Mbb[6 * (3 + j) + i] = c[i]; }
+      for (int i = 0; i < 3; i++) { Mbb[6 * i + 3 + j] = c[i]; }
       T[j] = Icb[0] * a[0] + Icb[3] * a[1] + Icb[4] * a[2];       // (I a_j), stored column-wise: T[3*r + j]
       T[3 + j] = Icb[3] * a[0] + Icb[1] * a[1] + Icb[5] * a[2];
       T[6 + j] = Icb[4] * a[0] + Icb[5] * a[1] + Icb[2] * a[2];
@@ -460,15 +465,14 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = i; j < 3; j++) {
-        real v = Rb[i] * T[j] + Rb[3 + i] * T[3 + j] + Rb[6 + i] * T[6 + j];
-        Mbb[6 * (3 + i) + 3 + j] = v; Mbb[6 * (3 + j) + 3 + i] = v;
-      }
+      for (int j = i; j < 3; j++) Mbb[6 * (3 + i) + 3 + j] = Rb[i] * T[j] + Rb[3 + i] * T[3 + j] + Rb[6 + i] * T[6 + j];
   }
+  wave_sync();
 
   // ---- block factorisations: M (pass 0) and M + h*kv*I on the actuated dofs (pass 1, implicitfast)
 #pragma unroll
   for (int pass = 0; pass < 2; pass++) {
+    sched_fence();
     vr Mh[6];
     real dg = pass ? M.h * M.kv : real(0);
     Mh[0] = Ml[0] + dg; Mh[1] = Ml[1]; Mh[2] = Ml[2]; Mh[3] = Ml[3] + dg; Mh[4] = Ml[4]; Mh[5] = Ml[5] + dg;
@@ -490,17 +494,17 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
     for (int k = 0; k < 3; k++)
 #pragma unroll
       for (int j = 0; j < 6; j++) stsv(shW, leg * 18 + (6 * k + j), W[k][j], isleg);
-    real Sc[36];
+    // Schur complement of the leg blocks (upper triangle, row-major in LDS)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
       for (int j = i; j < 6; j++) {
         vr cij = Mlb[0][i] * W[0][j] + Mlb[1][i] * W[1][j] + Mlb[2][i] * W[2][j];
-        real sc = Mbb[6 * i + j] - legsum<real>(cij, isleg);
-        Sc[6 * i + j] = sc; Sc[6 * j + i] = sc;
+        sh.sc[6 * i + j] = sh.mbb[6 * i + j] - legsum<real>(cij, isleg);
       }
+    wave_sync();
     real L[15], Di[6];
-    ldl6(Sc, L, Di);
+    ldl6(sh.sc, L, Di);
 #pragma unroll
     for (int j = 0; j < 15; j++) shL[j] = L[j];
 #pragma unroll

@@ -122,6 +122,8 @@ template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; 
 template <class T> NM_FN T gldv(const T* p, int i) { return p[i]; }
 template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) p[i] = v; }
 NM_FN void wave_sync() { __syncthreads(); }
+// keep the scheduler from hoisting a later phase's loads across this point (they would sit in VGPRs and spill)
+NM_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 }  // namespace simt
 
 #else
@@ -214,5 +216,6 @@ template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p,
 template <class T> NM_FN void gstv(T* p, const V<int>& i, const V<T>& v, const VB& m) { stsv(p, i, v, m); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, T v, const VB& m) { stsv(p, i, v, m); }
 NM_FN void wave_sync() {}
+NM_FN void sched_fence() {}
 }  // namespace simt
 #endif
