@@ -32,10 +32,10 @@ constexpr int kNQ = 25, kNV = 24, kNU = 18, kNLEG = 6, kNCOL = 7, kNSENS = 13, k
 constexpr int kLinkN = 25;             // per-link constants: bpos3 bR9 axis3 ipos3 Ibody6 mass1
 constexpr int kLegN = 3 * kLinkN;      // per-leg constants
 constexpr int kBaseN = 10;             // ipos3 Ibody6 mass1
-constexpr int kColN = 8;               // per colliding mesh: center3 rbound invweight0 nvert vadr pad
+constexpr int kColN = 24;              // per colliding mesh: center3 rbound invweight0 nvert vadr pad | obb: center3 axes9 half3 pad
 constexpr int kMaxCon = 16;            // contacts kept per env (rows = 4*kMaxCon = one per lane)
 constexpr int kMaxRow = 4 * kMaxCon;
-constexpr int kJRow = 12;              // LDS row: Jb6 Jl3 leg pad2
+constexpr int kJRow = 16;              // LDS row: Jb6 Jl3 leg | Jm3 leg1 (body1 side of a tibia-tibia contact) pad2
 enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
 
 // model + config constants, converted once to `real` by the host and kept in HBM/L2 (shared by all envs)
@@ -52,7 +52,8 @@ template <class real> struct Model {
   real h, kv, ctrl_max, grav, mu;
   real solref_K, solref_B, si_d0, si_dmax, si_width, si_mid, si_power;
   real pgs_scale, pgs_tol, noslip_tol, tol_planemesh;
-  int pgs_iters, noslip_iters;
+  int pgs_iters, noslip_iters, mpr_iters;
+  real mpr_tol;
   // env config (reference envs/nightmare_v3_config.py)
   real dt, p_gain, clip_obs, obs_lin, obs_ang, obs_dofpos, obs_dofvel, max_lin_x, max_ang, term_force, sigma, max_ep_len, default_pos[3];
   float action_scale, clip_actions;
@@ -96,8 +97,8 @@ template <class real> struct Sh {
   real Minv[kNLEG * 6], W[kNLEG * 18], Lb[15], Dbi[6];      // factor of M
   real MinvH[kNLEG * 6], WH[kNLEG * 18], LbH[15], DbiH[6];  // factor of M + h kv I
   real qas[24], qfs[24], qfc[24];
-  real cpos[kMaxCon * 3], cdist[kMaxCon];
-  int cleg[kMaxCon];
+  real cpos[kMaxCon * 3], cdist[kMaxCon], cnrm[kMaxCon * 3];
+  int cleg[kMaxCon], cleg1[kMaxCon];   // leg of body2 (-1 = base), leg of body1 (-1 = world/floor)
   real jrow[kMaxRow * kJRow];
   real sens[16], cvb[6];
   real mbb[36], sc[36];           // base block of M and its Schur complement (upper triangles)
@@ -106,7 +107,7 @@ template <class real> struct Sh {
 #ifdef NM_DEBUG_SOLVER
   real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
 #endif
-  int ncon, nwarn, it_pgs, it_noslip;
+  int ncon, nwarn, it_pgs, it_noslip, anypair;
 };
 
 // ----------------------------------------------------------------------------------------- small algebra
@@ -542,9 +543,303 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
   wave_sync();
 }
 
+
+// =========================================================================================  convex-convex (MPR)
+// Tibia vs tibia (contype 2 / conaffinity 3, reference mjmodel.xml:47...). Restates libccd's ccdMPRPenetration the way
+// MuJoCo 3.1.2's mjc_Convex drives it (centre = mesh COM, support = hull vertex of largest dot product, 50 iterations,
+// tolerance 1e-6, one contact per pair). The portal logic is wave-uniform scalar code; every support query is a
+// lane-parallel arg-max over the two hulls.
+template <class real> struct Sup { real v[3], v1[3], v2[3]; };
+template <class real> NM_FN real ccd_eps() { return sizeof(real) == 8 ? real(2.220446049250313e-16) : real(1.1920929e-7); }
+template <class real> NM_FN bool ccd_zero(real x) { return vabs(x) < ccd_eps<real>(); }
+template <class real> NM_FN bool ccd_eq(real a, real b) {
+  real ab = vabs(a - b);
+  if (ab < ccd_eps<real>()) return true;
+  real fa = vabs(a), fb = vabs(b);
+  return ab < ccd_eps<real>() * (fb > fa ? fb : fa);
+}
+template <class real> NM_FN void hull_support(const Sh<real>& sh, const Model<real>& M, int g, const real* dir, real* out) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const real* R = sh.colR + 9 * g;
+  const real* p = sh.colp + 3 * g;
+  const real* cc = M.colc + kColN * g;
+  const int nvert = (int)cc[5], vadr = (int)cc[6];
+  const real ld[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
+                      R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  // two passes: wave max, then the lowest vertex index within kMprTie of it (tie-robust, see oracle hull_support)
+  vr best = vr(real(-1e30));
+  for (int it = 0; it * NM_WAVE < nvert; it++) {
+    V<int> vi = lane + it * NM_WAVE;
+    VB ok = vi < nvert;
+    V<int> ad = (sel(ok, vi, V<int>(0)) + vadr) * 4;
+    vr val = ld[0] * gldv(M.hullv, ad) + ld[1] * gldv(M.hullv, ad + 1) + ld[2] * gldv(M.hullv, ad + 2);
+    best = sel(ok & (val > best), val, best);
+  }
+  real sv; int si;
+  wargmax(best, lane, &sv, &si);
+  vr neg = vr(real(-1e30));
+  V<int> ifirst = V<int>(1 << 30);
+  for (int it = 0; it * NM_WAVE < nvert; it++) {
+    V<int> vi = lane + it * NM_WAVE;
+    VB ok = vi < nvert;
+    V<int> ad = (sel(ok, vi, V<int>(0)) + vadr) * 4;
+    vr val = ld[0] * gldv(M.hullv, ad) + ld[1] * gldv(M.hullv, ad + 1) + ld[2] * gldv(M.hullv, ad + 2);
+    ifirst = sel(ok & (val >= vr(sv - real(1e-7))) & (vi < ifirst), vi, ifirst);
+  }
+  wargmax(to_real<real>(-ifirst), lane, &sv, &si);  // largest -index = lowest index
+  si = (int)(-sv);
+  const real* v = M.hullv + 4 * (vadr + si);
+  real t[3];
+  matvec3(t, R, v);
+  out[0] = p[0] + t[0]; out[1] = p[1] + t[1]; out[2] = p[2] + t[2];
+}
+template <class real> NM_FN void mpr_support(const Sh<real>& sh, const Model<real>& M, int g1, int g2, const real* dir, Sup<real>& s) {
+  real nd[3] = {-dir[0], -dir[1], -dir[2]};
+  hull_support(sh, M, g1, dir, s.v1);
+  hull_support(sh, M, g2, nd, s.v2);
+  s.v[0] = s.v1[0] - s.v2[0]; s.v[1] = s.v1[1] - s.v2[1]; s.v[2] = s.v1[2] - s.v2[2];
+}
+template <class real> NM_FN void sub3(real* r, const real* a, const real* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+template <class real> NM_FN void ccd_normalize(real* v) { real s = real(1) / vsqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] *= s; v[1] *= s; v[2] *= s; }
+template <class real> NM_FN void portal_dir(const Sup<real>* p, real* dir) {
+  real a[3], b[3];
+  sub3(a, p[2].v, p[1].v); sub3(b, p[3].v, p[1].v);
+  cross3(dir, a, b);
+  ccd_normalize(dir);
+}
+template <class real> NM_FN bool portal_reach_tol(const Sup<real>* p, const Sup<real>& v4, const real* dir, real tol) {
+  real dv4 = dot3<real>(v4.v, dir);
+  real d1 = dv4 - dot3<real>(p[1].v, dir), d2 = dv4 - dot3<real>(p[2].v, dir), d3 = dv4 - dot3<real>(p[3].v, dir);
+  real m = vmin(vmin(d1, d2), d3);
+  return ccd_eq(m, tol) || m < tol;
+}
+template <class real> NM_FN void expand_portal(Sup<real>* p, const Sup<real>& v4) {
+  real v4v0[3];
+  cross3(v4v0, v4.v, p[0].v);
+  if (dot3<real>(p[1].v, v4v0) > real(0)) {
+    if (dot3<real>(p[2].v, v4v0) > real(0)) p[1] = v4; else p[3] = v4;
+  } else {
+    if (dot3<real>(p[3].v, v4v0) > real(0)) p[2] = v4; else p[1] = v4;
+  }
+}
+template <class real> NM_FN real point_seg_dist2(const real* x0, const real* b, real* wit) {  // point P = origin
+  real dd[3];
+  sub3(dd, b, x0);
+  real t = -dot3<real>(x0, dd) / dot3<real>(dd, dd);
+  if (t < real(0) || ccd_zero(t)) { wit[0] = x0[0]; wit[1] = x0[1]; wit[2] = x0[2]; }
+  else if (t > real(1) || ccd_eq(t, real(1))) { wit[0] = b[0]; wit[1] = b[1]; wit[2] = b[2]; }
+  else { wit[0] = x0[0] + t * dd[0]; wit[1] = x0[1] + t * dd[1]; wit[2] = x0[2] + t * dd[2]; }
+  return dot3<real>(wit, wit);
+}
+template <class real> NM_FN real point_tri_dist2(const real* x0, const real* B, const real* C, real* wit) {  // point P = origin
+  real d1[3], d2[3];
+  sub3(d1, B, x0); sub3(d2, C, x0);
+  real v = dot3<real>(d1, d1), w = dot3<real>(d2, d2), p = dot3<real>(x0, d1), q = dot3<real>(x0, d2), r = dot3<real>(d1, d2);
+  real dd = w * v - r * r, s, t;
+  if (ccd_zero(dd)) { s = real(-1); t = real(-1); }
+  else { s = (q * r - w * p) / dd; t = (-s * r - q) / w; }
+  if ((ccd_zero(s) || s > real(0)) && (ccd_eq(s, real(1)) || s < real(1)) && (ccd_zero(t) || t > real(0)) && (ccd_eq(t, real(1)) || t < real(1)) &&
+      (ccd_eq(t + s, real(1)) || t + s < real(1))) {
+    wit[0] = x0[0] + s * d1[0] + t * d2[0]; wit[1] = x0[1] + s * d1[1] + t * d2[1]; wit[2] = x0[2] + s * d1[2] + t * d2[2];
+    return dot3<real>(wit, wit);
+  }
+  real w2[3];
+  real dist = point_seg_dist2(x0, B, wit);
+  real dist2 = point_seg_dist2(x0, C, w2);
+  if (dist2 < dist) { dist = dist2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; }
+  dist2 = point_seg_dist2(B, C, w2);
+  if (dist2 < dist) { dist = dist2; wit[0] = w2[0]; wit[1] = w2[1]; wit[2] = w2[2]; }
+  return dist;
+}
+// true and (depth, dir from geom1 to geom2, pos) when the two hulls penetrate
+template <class real> NM_FN bool mpr_penetration(const Sh<real>& sh, const Model<real>& M, int g1, int g2, real* depth, real* dir_out, real* pos) {
+  Sup<real> p[4], v4;
+  real dir[3], va[3], vb[3], dot;
+  {  // discoverPortal: v0 = centre1 - centre2
+    const real *R1 = sh.colR + 9 * g1, *R2 = sh.colR + 9 * g2, *c1 = M.colc + kColN * g1, *c2 = M.colc + kColN * g2;
+    real t1[3], t2[3];
+    matvec3(t1, R1, c1); matvec3(t2, R2, c2);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      p[0].v1[k] = sh.colp[3 * g1 + k] + t1[k];
+      p[0].v2[k] = sh.colp[3 * g2 + k] + t2[k];
+      p[0].v[k] = p[0].v1[k] - p[0].v2[k];
+    }
+  }
+  if (ccd_eq(p[0].v[0], real(0)) && ccd_eq(p[0].v[1], real(0)) && ccd_eq(p[0].v[2], real(0))) p[0].v[0] += ccd_eps<real>() * real(10);
+  dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
+  ccd_normalize(dir);
+  mpr_support(sh, M, g1, g2, dir, p[1]);
+  dot = dot3<real>(p[1].v, dir);
+  if (ccd_zero(dot) || dot < real(0)) return false;
+  cross3(dir, p[0].v, p[1].v);
+  if (ccd_zero(dot3<real>(dir, dir))) {
+    if (ccd_eq(p[1].v[0], real(0)) && ccd_eq(p[1].v[1], real(0)) && ccd_eq(p[1].v[2], real(0))) return false;  // touching: direction undefined
+    *depth = vsqrt(dot3<real>(p[1].v, p[1].v));   // origin on the v0-v1 segment
+    dir_out[0] = p[1].v[0]; dir_out[1] = p[1].v[1]; dir_out[2] = p[1].v[2];
+    ccd_normalize(dir_out);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pos[k] = real(0.5) * (p[1].v1[k] + p[1].v2[k]);
+    return true;
+  }
+  ccd_normalize(dir);
+  mpr_support(sh, M, g1, g2, dir, p[2]);
+  dot = dot3<real>(p[2].v, dir);
+  if (ccd_zero(dot) || dot < real(0)) return false;
+  sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
+  cross3(dir, va, vb);
+  ccd_normalize(dir);
+  if (dot3<real>(dir, p[0].v) > real(0)) {
+    Sup<real> t = p[1]; p[1] = p[2]; p[2] = t;
+    dir[0] = -dir[0]; dir[1] = -dir[1]; dir[2] = -dir[2];
+  }
+  for (int size = 3, guard = 0; size < 4; guard++) {
+    if (guard > 64) return false;
+    mpr_support(sh, M, g1, g2, dir, p[3]);
+    dot = dot3<real>(p[3].v, dir);
+    if (ccd_zero(dot) || dot < real(0)) return false;
+    bool cont = false;
+    cross3(va, p[1].v, p[3].v);
+    dot = dot3<real>(va, p[0].v);
+    if (dot < real(0) && !ccd_zero(dot)) { p[2] = p[3]; cont = true; }
+    if (!cont) {
+      cross3(va, p[3].v, p[2].v);
+      dot = dot3<real>(va, p[0].v);
+      if (dot < real(0) && !ccd_zero(dot)) { p[1] = p[3]; cont = true; }
+    }
+    if (cont) {
+      sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
+      cross3(dir, va, vb);
+      ccd_normalize(dir);
+    } else size = 4;
+  }
+  for (int guard = 0;; guard++) {  // refinePortal
+    portal_dir(p, dir);
+    dot = dot3<real>(dir, p[1].v);
+    if (ccd_zero(dot) || dot > real(0)) break;
+    if (guard > 100) return false;
+    mpr_support(sh, M, g1, g2, dir, v4);
+    dot = dot3<real>(v4.v, dir);
+    if (!(ccd_zero(dot) || dot > real(0)) || portal_reach_tol(p, v4, dir, M.mpr_tol)) return false;
+    expand_portal(p, v4);
+  }
+  for (int it = 0;; it++) {  // findPenetr
+    portal_dir(p, dir);
+    mpr_support(sh, M, g1, g2, dir, v4);
+    if (portal_reach_tol(p, v4, dir, M.mpr_tol) || it > M.mpr_iters) {
+      real pd[3];
+      *depth = vsqrt(point_tri_dist2(p[1].v, p[2].v, p[3].v, pd));
+      if (ccd_zero(pd[0]) && ccd_zero(pd[1]) && ccd_zero(pd[2])) { pd[0] = dir[0]; pd[1] = dir[1]; pd[2] = dir[2]; }
+      ccd_normalize(pd);
+      dir_out[0] = pd[0]; dir_out[1] = pd[1]; dir_out[2] = pd[2];
+      real b[4], t[3], sum;  // findPos: barycentric coordinates of the origin in the portal tetrahedron
+      portal_dir(p, dir);
+      cross3(t, p[1].v, p[2].v); b[0] = dot3<real>(t, p[3].v);
+      cross3(t, p[3].v, p[2].v); b[1] = dot3<real>(t, p[0].v);
+      cross3(t, p[0].v, p[1].v); b[2] = dot3<real>(t, p[3].v);
+      cross3(t, p[2].v, p[1].v); b[3] = dot3<real>(t, p[0].v);
+      sum = b[0] + b[1] + b[2] + b[3];
+      if (ccd_zero(sum) || sum < real(0)) {
+        b[0] = real(0);
+        cross3(t, p[2].v, p[3].v); b[1] = dot3<real>(t, dir);
+        cross3(t, p[3].v, p[1].v); b[2] = dot3<real>(t, dir);
+        cross3(t, p[1].v, p[2].v); b[3] = dot3<real>(t, dir);
+        sum = b[1] + b[2] + b[3];
+      }
+      real inv = real(1) / sum;
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        real p1 = b[0] * p[0].v1[k] + b[1] * p[1].v1[k] + b[2] * p[2].v1[k] + b[3] * p[3].v1[k];
+        real p2 = b[0] * p[0].v2[k] + b[1] * p[1].v2[k] + b[2] * p[2].v2[k] + b[3] * p[3].v2[k];
+        pos[k] = real(0.5) * (p1 * inv + p2 * inv);
+      }
+      return true;
+    }
+    expand_portal(p, v4);
+  }
+}
+
+// tibia-tibia pairs: lanes 0..14 run the cull (MuJoCo's bounding-sphere filter AND a conservative separating-axis test of
+// the two hull OBBs along the line of centres); surviving pairs go through MPR one at a time.
+template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<real>& M, int* dropped) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const VB isp = lane < 15;
+  const V<int> pl = sel(isp, lane, V<int>(0));
+  V<int> i1 = sel(pl >= 5, V<int>(1), V<int>(0)) + sel(pl >= 9, V<int>(1), V<int>(0)) + sel(pl >= 12, V<int>(1), V<int>(0)) +
+              sel(pl >= 14, V<int>(1), V<int>(0));                       // 0..4
+  V<int> st = sel(i1 == 0, V<int>(0), sel(i1 == 1, V<int>(5), sel(i1 == 2, V<int>(9), sel(i1 == 3, V<int>(12), V<int>(14)))));
+  V<int> g1 = i1 + 1, g2 = g1 + 1 + (pl - st);
+  vr c1[3], c2[3], e[2];
+  V<int> gg[2] = {g1, g2};
+  vr u[3];
+#pragma unroll
+  for (int w = 0; w < 2; w++) {
+    vr R[9], oc[3], c[3];
+#pragma unroll
+    for (int j = 0; j < 9; j++) R[j] = ldsv(sh.colR, gg[w] * 9 + j);
+#pragma unroll
+    for (int j = 0; j < 3; j++) oc[j] = gldv(M.colc, gg[w] * kColN + (8 + j));
+    matvec3(c, R, oc);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { c[j] = c[j] + ldsv(sh.colp, gg[w] * 3 + j); if (w == 0) c1[j] = c[j]; else c2[j] = c[j]; }
+  }
+  u[0] = c2[0] - c1[0]; u[1] = c2[1] - c1[1]; u[2] = c2[2] - c1[2];
+  vr dist = vsqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  vr inv = vr(real(1)) / vmax(dist, vr(real(1e-12)));
+  u[0] = u[0] * inv; u[1] = u[1] * inv; u[2] = u[2] * inv;
+#pragma unroll
+  for (int w = 0; w < 2; w++) {  // extent of each OBB along u: sum_i h_i |u . (R a_i)|
+    vr R[9], ul[3];
+#pragma unroll
+    for (int j = 0; j < 9; j++) R[j] = ldsv(sh.colR, gg[w] * 9 + j);
+    ul[0] = R[0] * u[0] + R[3] * u[1] + R[6] * u[2]; ul[1] = R[1] * u[0] + R[4] * u[1] + R[7] * u[2]; ul[2] = R[2] * u[0] + R[5] * u[1] + R[8] * u[2];
+    vr ext = vr(real(0));
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      vr ax[3] = {gldv(M.colc, gg[w] * kColN + (11 + 3 * a)), gldv(M.colc, gg[w] * kColN + (12 + 3 * a)), gldv(M.colc, gg[w] * kColN + (13 + 3 * a))};
+      ext += gldv(M.colc, gg[w] * kColN + (20 + a)) * vabs(ax[0] * ul[0] + ax[1] * ul[1] + ax[2] * ul[2]);
+    }
+    e[w] = ext;
+  }
+  // MuJoCo's sphere filter is on the mesh COMs; it is implied by the (tighter) OBB test in practice, but keep both exact-conservative
+  uint64_t m = ballot(isp & !(dist > e[0] + e[1]));
+  int ncon = sh.ncon;
+  while (m) {
+    int pidx = __builtin_ctzll(m);
+    m &= m - 1;
+    int a = (pidx >= 5) + (pidx >= 9) + (pidx >= 12) + (pidx >= 14);
+    int s0 = a == 0 ? 0 : (a == 1 ? 5 : (a == 2 ? 9 : (a == 3 ? 12 : 14)));
+    int h1 = a + 1, h2 = h1 + 1 + (pidx - s0);
+    {  // mj_filterSphere on the COM-centred bounding spheres
+      const real *R1 = sh.colR + 9 * h1, *R2 = sh.colR + 9 * h2, *k1 = M.colc + kColN * h1, *k2 = M.colc + kColN * h2;
+      real t1[3], t2[3], dd[3];
+      matvec3(t1, R1, k1); matvec3(t2, R2, k2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) dd[k] = (sh.colp[3 * h1 + k] + t1[k]) - (sh.colp[3 * h2 + k] + t2[k]);
+      real bound = k1[3] + k2[3];
+      if (dot3<real>(dd, dd) > bound * bound) continue;
+    }
+    real depth, dir[3], pos[3];
+    if (!mpr_penetration(sh, M, h1, h2, &depth, dir, pos)) continue;
+    if (!(depth > real(0))) continue;
+    if (ncon >= kMaxCon) { *dropped += 1; continue; }
+    sh.cpos[3 * ncon] = pos[0]; sh.cpos[3 * ncon + 1] = pos[1]; sh.cpos[3 * ncon + 2] = pos[2];
+    sh.cnrm[3 * ncon] = dir[0]; sh.cnrm[3 * ncon + 1] = dir[1]; sh.cnrm[3 * ncon + 2] = dir[2];
+    sh.cdist[ncon] = -depth;
+    sh.cleg[ncon] = h2 - 1;
+    sh.cleg1[ncon] = h1 - 1;
+    sh.anypair = 1;
+    ncon++;
+  }
+  sh.ncon = ncon;
+  wave_sync();
+}
+
 // =========================================================================================  stage B
 // Floor (z = 0) against the convex hulls of base_link and the six tibias.
-template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped) {
+template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped, bool pairs = true) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   int ncon = 0;
@@ -585,6 +880,8 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     sh.cpos[3 * ncon] = first[0]; sh.cpos[3 * ncon + 1] = first[1]; sh.cpos[3 * ncon + 2] = first[2];
     sh.cdist[ncon] = dist;
     sh.cleg[ncon] = g - 1;
+    sh.cleg1[ncon] = -1;
+    sh.cnrm[3 * ncon] = real(0); sh.cnrm[3 * ncon + 1] = real(0); sh.cnrm[3 * ncon + 2] = real(1);
     ncon++;
     // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
     const real tol = M.tol_planemesh * cc[3];
@@ -612,16 +909,20 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       stsv(sh.cpos, V<int>(3 * ncon + 2), pnt[2] - real(0.5) * cd, me);
       stsv(sh.cdist, V<int>(ncon), cd, me);
       sh.cleg[ncon] = g - 1;
+      sh.cleg1[ncon] = -1;
+      sh.cnrm[3 * ncon] = real(0); sh.cnrm[3 * ncon + 1] = real(0); sh.cnrm[3 * ncon + 2] = real(1);
       ncon++;
     }
   }
   sh.ncon = ncon;
+  sh.anypair = 0;
   wave_sync();
+  if (pairs) stage_collide_pairs(sh, M, dropped);
 }
 
 // =========================================================================================  stage C
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
-template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep = false) {
+template <class real, bool PAIR> NM_FN void stage_constraint_impl(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const int ncon = uniform(sh.ncon), nefc = 4 * ncon;
@@ -642,12 +943,30 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
   V<int> L = ldsv(sh.cleg, c);
   const VB onleg = L >= 0;
   const V<int> Lc = vmax(L, V<int>(0));
-  // pyramid edge direction for the floor frame n=(0,0,1), t1=(0,1,0), t2=(-1,0,0): d = n +- mu t_k
+  // tibia-tibia contacts (rare) carry a second leg (body1) and a general frame; floor-only envs skip all of that
+  constexpr bool anypair = PAIR;  // floor-only envs (the common case) compile without the second-body terms
+  V<int> L1 = V<int>(-1);
+  if (anypair) L1 = ldsv(sh.cleg1, c);
+  const VB onleg1 = L1 >= 0;
+  const V<int> Lc1 = vmax(L1, V<int>(0));
+  // pyramid edge direction d = n +- mu t_k; floor frame n=(0,0,1), t1=(0,1,0), t2=(-1,0,0) (mju_makeFrame)
   vr smu = sel(sg == 0, vr(M.mu), vr(-M.mu));
-  vr d[3];
+  vr d[3], nrm[3] = {vr(real(0)), vr(real(0)), vr(real(1))};
   d[0] = sel(tk == 1, -smu, vr(real(0)));
   d[1] = sel(tk == 0, smu, vr(real(0)));
   d[2] = vr(real(1));
+  if (anypair) {
+    nrm[0] = ldsv(sh.cnrm, c * 3); nrm[1] = ldsv(sh.cnrm, c * 3 + 1); nrm[2] = ldsv(sh.cnrm, c * 3 + 2);
+    VB usey = (nrm[1] < vr(real(0.5))) & (nrm[1] > vr(real(-0.5)));
+    vr y0[3] = {vr(real(0)), sel(usey, vr(real(1)), vr(real(0))), sel(usey, vr(real(0)), vr(real(1)))};
+    vr dt = nrm[1] * y0[1] + nrm[2] * y0[2];
+    vr t1[3] = {y0[0] - dt * nrm[0], y0[1] - dt * nrm[1], y0[2] - dt * nrm[2]}, t2[3];
+    vr il = vr(real(1)) / vsqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+    t1[0] = t1[0] * il; t1[1] = t1[1] * il; t1[2] = t1[2] * il;
+    cross3(t2, nrm, t1);
+#pragma unroll
+    for (int j = 0; j < 3; j++) d[j] = nrm[j] + smu * sel(tk == 0, t1[j], t2[j]);
+  }
   // Jacobian row: base translation, base rotation (body axes), the 3 hinges of the contact's own leg
   vr Jb[6], Jl[3];
   {
@@ -669,6 +988,23 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
       Jl[k] = sel(onleg, dot3<vr>(a, mm), vr(real(0)));
     }
   }
+  vr Jm[3] = {vr(real(0)), vr(real(0)), vr(real(0))};  // body1 side: -J(body1); the base columns of J(b2) - J(b1) cancel exactly
+  if (anypair) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vr a[3], r[3], rel[3], mm[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        a[j] = ldsv(sh.axs, Lc1 * 9 + (3 * k + j));
+        r[j] = ldsv(sh.anc, Lc1 * 9 + (3 * k + j));
+        rel[j] = cp[j] - r[j];
+      }
+      cross3(mm, rel, d);
+      Jm[k] = sel(onleg1 & act, -dot3<vr>(a, mm), vr(real(0)));
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) Jb[j] = sel(onleg1, vr(real(0)), Jb[j]);
+  }
 #pragma unroll
   for (int j = 0; j < 6; j++) Jb[j] = sel(act, Jb[j], vr(real(0)));
 #pragma unroll
@@ -679,6 +1015,11 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
 #pragma unroll
   for (int k = 0; k < 3; k++) stsv(sh.jrow, lane * kJRow + (6 + k), Jl[k], lane < kMaxRow);
   stsv(sh.jrow, lane * kJRow + 9, to_real<real>(L), lane < kMaxRow);
+  if (anypair) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) stsv(sh.jrow, lane * kJRow + (10 + k), Jm[k], lane < kMaxRow);
+    stsv(sh.jrow, lane * kJRow + 13, to_real<real>(L1), lane < kMaxRow);
+  }
 
   // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
   vr imp;
@@ -692,6 +1033,7 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
     imp = sel(x <= vr(real(0)), vr(M.si_d0), imp);
   }
   vr invw = gldv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
+  if (anypair) invw = invw + sel(onleg1, gldv(M.colc, (Lc1 + 1) * kColN + 4), vr(real(0)));
   vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
   vr Dd = vr(real(1)) / Rr;
   // sparse dots with the wave-uniform vectors qvel, qacc_smooth, qacc_warmstart
@@ -705,6 +1047,13 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
     V<int> di = Lc * 3 + (6 + k);
     vel += Jl[k] * ldsv(sh.qvel, di); jas += Jl[k] * ldsv(sh.qas, di); jaw += Jl[k] * ldsv(sh.warm, di);
   }
+  if (anypair) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      V<int> di = Lc1 * 3 + (6 + k);
+      vel += Jm[k] * ldsv(sh.qvel, di); jas += Jm[k] * ldsv(sh.qas, di); jaw += Jm[k] * ldsv(sh.warm, di);
+    }
+  }
   vr aref = -M.solref_B * vel - M.solref_K * imp * dist;
   vr bb = jas - aref;
 
@@ -715,12 +1064,23 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
 #pragma unroll
     for (int j = 0; j < 6; j++) Mi[j] = ldsv(sh.Minv, Lc * 6 + j);
     ldl3_solve(t, Mi, Jl);
+    vr t1m[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
     vr xb[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
       xb[j] = Jb[j];
 #pragma unroll
       for (int k = 0; k < 3; k++) xb[j] = xb[j] - ldsv(sh.W, Lc * 18 + (6 * k + j)) * Jl[k];
+    }
+    if (anypair) {
+      vr Mi1[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) Mi1[j] = ldsv(sh.Minv, Lc1 * 6 + j);
+      ldl3_solve(t1m, Mi1, Jm);
+#pragma unroll
+      for (int j = 0; j < 6; j++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) xb[j] = xb[j] - ldsv(sh.W, Lc1 * 18 + (6 * k + j)) * Jm[k];
     }
     ldl6_solve(sh.Lb, sh.Dbi, xb);
 #pragma unroll
@@ -730,6 +1090,7 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         vr x = sel(L == l, t[k], vr(real(0)));
+        if (anypair) x = x + sel(L1 == l, t1m[k], vr(real(0)));
 #pragma unroll
         for (int j = 0; j < 6; j++) x = x - sh.W[l * 18 + 6 * k + j] * xb[j];
         B[6 + 3 * l + k] = x;
@@ -754,6 +1115,18 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
         case 5: a += jr[6] * B[21] + jr[7] * B[22] + jr[8] * B[23]; break;
         default: break;
       }
+      if (anypair) {
+        const int L1i = uniform((int)jr[13]);
+        switch (L1i) {
+          case 0: a += jr[10] * B[6] + jr[11] * B[7] + jr[12] * B[8]; break;
+          case 1: a += jr[10] * B[9] + jr[11] * B[10] + jr[12] * B[11]; break;
+          case 2: a += jr[10] * B[12] + jr[11] * B[13] + jr[12] * B[14]; break;
+          case 3: a += jr[10] * B[15] + jr[11] * B[16] + jr[12] * B[17]; break;
+          case 4: a += jr[10] * B[18] + jr[11] * B[19] + jr[12] * B[20]; break;
+          case 5: a += jr[10] * B[21] + jr[11] * B[22] + jr[12] * B[23]; break;
+          default: break;
+        }
+      }
       A[i] = a;
     }
   }
@@ -761,6 +1134,9 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
   vr Ajj = Jb[0] * B[0] + Jb[1] * B[1] + Jb[2] * B[2] + Jb[3] * B[3] + Jb[4] * B[4] + Jb[5] * B[5];
 #pragma unroll
   for (int l = 0; l < 6; l++) Ajj += sel(L == l, Jl[0] * B[6 + 3 * l] + Jl[1] * B[7 + 3 * l] + Jl[2] * B[8 + 3 * l], vr(real(0)));
+  if (anypair)
+#pragma unroll
+    for (int l = 0; l < 6; l++) Ajj += sel(L1 == l, Jm[0] * B[6 + 3 * l] + Jm[1] * B[7 + 3 * l] + Jm[2] * B[8 + 3 * l], vr(real(0)));
   vr ARjj = Ajj + Rr;
   vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
 
@@ -840,38 +1216,48 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real
 #pragma unroll
   for (int l = 0; l < 6; l++)
 #pragma unroll
-    for (int k = 0; k < 3; k++) sh.qfc[6 + 3 * l + k] = wsum<real>(sel(L == l, Jl[k] * f, vr(real(0))));
+    for (int k = 0; k < 3; k++) sh.qfc[6 + 3 * l + k] = wsum<real>(sel(L == l, Jl[k] * f, vr(real(0))) + sel(L1 == l, Jm[k] * f, vr(real(0))));
   // ---- touch sensors (only the last forward pass is observable after mj_step)
   if (last) {
     vr nf = f + shfl_xor1(f);
     nf = nf + shfl_xor2(nf);  // contact normal force = sum of its 4 pyramid edge forces
     VB head = act & ((lane & 3) == 0) & (nf > vr(real(0)));
-    // foot site sphere: ray from the contact point along -normal must hit it
-    vr ft[3], fr;
-    {
-      vr s[3], Rt[9];
+    // foot site sphere (mjmodel.xml:49...): the ray from the contact point along -normal (sensor on body2) or +normal
+    // (sensor on body1) must hit it (mju_rayGeom, sphere)
+    auto foot_hit = [&](const V<int>& Lx, real sgn) {
+      vr ft[3], fr, s[3], Rt[9];
 #pragma unroll
-      for (int j = 0; j < 3; j++) s[j] = gldv(M.footc, Lc * 4 + j);
-      fr = gldv(M.footc, Lc * 4 + 3);
+      for (int j = 0; j < 3; j++) s[j] = gldv(M.footc, Lx * 4 + j);
+      fr = gldv(M.footc, Lx * 4 + 3);
 #pragma unroll
-      for (int j = 0; j < 9; j++) Rt[j] = ldsv(sh.colR, (Lc + 1) * 9 + j);
+      for (int j = 0; j < 9; j++) Rt[j] = ldsv(sh.colR, (Lx + 1) * 9 + j);
       matvec3(ft, Rt, s);
 #pragma unroll
-      for (int j = 0; j < 3; j++) ft[j] = ft[j] + ldsv(sh.colp, (Lc + 1) * 3 + j);
-    }
-    vr dif[3] = {cp[0] - ft[0], cp[1] - ft[1], cp[2] - ft[2]};
-    vr b2 = -dif[2], cc = dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2] - fr * fr;
-    vr det = b2 * b2 - cc;
-    vr sq = vsqrt(vmax(det, vr(real(0))));
-    VB hit = !(det < vr(real(1e-15))) & (((-b2 - sq) >= vr(real(0))) | ((-b2 + sq) >= vr(real(0))));
+      for (int j = 0; j < 3; j++) ft[j] = ft[j] + ldsv(sh.colp, (Lx + 1) * 3 + j);
+      vr dif[3] = {cp[0] - ft[0], cp[1] - ft[1], cp[2] - ft[2]};
+      vr b2 = sgn * (nrm[0] * dif[0] + nrm[1] * dif[1] + nrm[2] * dif[2]);
+      vr cc = dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2] - fr * fr;
+      vr det = b2 * b2 - cc;
+      vr sq = vsqrt(vmax(det, vr(real(0))));
+      return !(det < vr(real(1e-15))) & (((-b2 - sq) >= vr(real(0))) | ((-b2 + sq) >= vr(real(0))));
+    };
+    VB hit = foot_hit(Lc, real(-1));
+    VB hit1 = VB(false);
+    if (anypair) hit1 = foot_hit(Lc1, real(1));
 #pragma unroll
     for (int l = 0; l < 6; l++) {
-      sh.sens[l] = wsum<real>(sel(head & (L == l), nf, vr(real(0))));          // tibia sites: 10 m spheres see every contact
-      sh.sens[6 + l] = wsum<real>(sel(head & (L == l) & hit, nf, vr(real(0))));  // foot sites
+      VB on = (L == l) | (L1 == l);
+      sh.sens[l] = wsum<real>(sel(head & on, nf, vr(real(0))));          // tibia sites: 10 m spheres see every contact of the body
+      sh.sens[6 + l] = wsum<real>(sel(head & (((L == l) & hit) | ((L1 == l) & hit1)), nf, vr(real(0))));  // foot sites
     }
     sh.sens[12] = wsum<real>(sel(head & (L < 0), nf, vr(real(0))));
   }
   wave_sync();
+}
+
+template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep = false) {
+  if (uniform(sh.anypair) != 0) stage_constraint_impl<real, true>(sh, M, last, nosweep);
+  else stage_constraint_impl<real, false>(sh, M, last, nosweep);
 }
 
 // =========================================================================================  stage D
@@ -988,8 +1374,8 @@ template <class real> NM_FN void substep(Sh<real>& sh, const Model<real>& M, boo
   }
   for (int attempt = 0; attempt < 2; attempt++) {
     if (!(ablate & 8)) stage_smooth(sh, M, last);
-    if (!(ablate & 1)) stage_collide(sh, M, dropped); else { sh.ncon = 0; wave_sync(); }
-    if (ablate & 4) { sh.ncon = 0; wave_sync(); }
+    if (!(ablate & 1)) stage_collide(sh, M, dropped, !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
+    if (ablate & 4) { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     stage_constraint(sh, M, last, (ablate & 2) != 0);
     bool bad = stage_integrate(sh, M);
     if (!bad) break;
@@ -1052,6 +1438,7 @@ template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, co
     gstv(dbg, V<int>(160), to_real<real>(sh.ncon), lane == 0);
     gstv(dbg, V<int>(161), to_real<real>(sh.nwarn), lane == 0);
     gstv(dbg, V<int>(162), to_real<real>(dropped), lane == 0);
+    gstv(dbg, lane + 165, ldsv(sh.cnrm, sel(lane < 6, lane, V<int>(0))), lane < 6);
     gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
     gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
     gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);

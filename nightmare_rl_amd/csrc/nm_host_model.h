@@ -85,6 +85,9 @@ template <class real> struct Tables {
       c[4] = (real)nm_body_invweight0[nm_col_body[g]][0];
       c[5] = (real)nm_col_nvert[g];
       c[6] = (real)nm_col_vadr[g];
+      for (int j = 0; j < 3; j++) c[8 + j] = (real)nm_col_obb_center[g][j];
+      for (int j = 0; j < 9; j++) c[11 + j] = (real)nm_col_obb_axes[g][j];
+      for (int j = 0; j < 3; j++) c[20 + j] = (real)nm_col_obb_half[g][j];
     }
     hullv.assign((size_t)NM_NHULLVERT * 4, real(0));
     for (int i = 0; i < NM_NHULLVERT; i++)
@@ -113,6 +116,7 @@ template <class real> struct Tables {
     M.pgs_scale = (real)(1.0 / (NM_MEANINERTIA * NM_NV));
     M.pgs_tol = (real)NM_TOLERANCE; M.noslip_tol = (real)NM_NOSLIP_TOLERANCE; M.tol_planemesh = (real)0.3;
     M.pgs_iters = NM_ITERATIONS; M.noslip_iters = NM_NOSLIP_ITERATIONS;
+    M.mpr_iters = 50; M.mpr_tol = (real)1e-6;  // MuJoCo 3.1.2 defaults opt.mpr_iterations / opt.mpr_tolerance
     double dt = NM_TIMESTEP * cfg.decimation;                       // env.py:99
     M.dt = (real)dt; M.p_gain = (real)cfg.p_gain; M.clip_obs = (real)cfg.clip_observations;
     M.obs_lin = (real)cfg.obs_lin_vel; M.obs_ang = (real)cfg.obs_ang_vel; M.obs_dofpos = (real)cfg.obs_dof_pos; M.obs_dofvel = (real)cfg.obs_dof_vel;

@@ -384,7 +384,13 @@ def compile_model(xml_path):
             rb = np.linalg.norm(np.max(np.abs(Vp), axis=0))
             vid, nbr = hull_with_graph(V)
             Vb = g["pos"] + V[vid] @ Rg.T  # hull vertices in the BODY frame
-            col.append(dict(body=b, name=g["name"], verts=Vb, nbr=nbr, rbound=rb, center=ipos[b].copy(),
+            # oriented bounding box of the hull in the mesh's principal frame -> body frame (conservative pair cull on the GPU)
+            Hp = (V[vid] - com) @ U
+            lo, hi = Hp.min(axis=0), Hp.max(axis=0)
+            obb_c = g["pos"] + Rg @ (com + U @ ((lo + hi) / 2))
+            obb_ax = (Rg @ U).T            # rows = box axes in the body frame
+            obb_h = (hi - lo) / 2
+            col.append(dict(body=b, name=g["name"], verts=Vb, nbr=nbr, rbound=rb, center=ipos[b].copy(), obb_c=obb_c, obb_ax=obb_ax, obb_h=obb_h,
                             contype=g["contype"], conaffinity=g["conaffinity"]))
     scale = mj["settotalmass"] / mass.sum()
     mass *= scale
@@ -400,6 +406,9 @@ def compile_model(xml_path):
     T["col_body"] = np.array([c["body"] for c in col], dtype=np.int32)
     T["col_rbound"] = np.array([c["rbound"] for c in col])
     T["col_center"] = np.array([c["center"] for c in col])
+    T["col_obb_center"] = np.array([c["obb_c"] for c in col])
+    T["col_obb_axes"] = np.array([c["obb_ax"].reshape(9) for c in col])
+    T["col_obb_half"] = np.array([c["obb_h"] for c in col])
     T["col_nvert"] = np.array([len(c["verts"]) for c in col], dtype=np.int32)
     T["col_vadr"] = np.concatenate([[0], np.cumsum(T["col_nvert"])[:-1]]).astype(np.int32)
     T["hull_vert"] = np.concatenate([c["verts"] for c in col])
@@ -492,7 +501,7 @@ def emit_header(T, path):
     for k in ("body_parent", "col_body", "col_nvert", "col_vadr", "sens_body", "hull_nbr"):
         out.append(c_array("nm_" + k, T[k], "int"))
     for k in ("body_pos", "body_quat", "body_ipos", "body_iquat", "body_mass", "body_inertia", "jnt_axis", "col_rbound",
-              "col_center", "hull_vert", "sens_pos", "sens_radius", "gravity", "solref", "solimp", "qpos0", "body_invweight0"):
+              "col_center", "col_obb_center", "col_obb_axes", "col_obb_half", "hull_vert", "sens_pos", "sens_radius", "gravity", "solref", "solimp", "qpos0", "body_invweight0"):
         out.append(c_array("nm_" + k, T[k], "double"))
     out.append("#endif /* NM_NO_TABLES */\n#endif\n")
     with open(path, "w") as f:

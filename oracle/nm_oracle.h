@@ -46,7 +46,7 @@ typedef struct {
   /* contacts */
   int32_t ncon, nefc;
   double con_pos[NMO_MAXCON][3], con_frame[NMO_MAXCON][9], con_dist[NMO_MAXCON];
-  int32_t con_body[NMO_MAXCON], con_geom[NMO_MAXCON];
+  int32_t con_body[NMO_MAXCON], con_body1[NMO_MAXCON], con_geom[NMO_MAXCON]; /* body2, body1 (0 = world), colliding-mesh index of geom2 */
   double efc_force[NMO_MAXEFC];
   double sensordata[NMO_NSENS];
   int32_t solver_niter, noslip_niter, nwarning, pad;

@@ -21,7 +21,7 @@
 #define MJ_MAXVAL 1e10
 #define TOL_PLANEMESH 0.3 /* engine_collision_convex.c: extra plane-mesh points at least this * rbound from the first */
 
-static int g_collide_self = 0;
+static int g_collide_self = 1;
 void nmo_set_collide_self(int on) { g_collide_self = on; }
 int nmo_sizeof_data(void) { return (int)sizeof(nmo_data); }
 int nmo_sizeof_scratch(void) { return (int)sizeof(nmo_scratch); }
@@ -254,7 +254,7 @@ static void make_frame(double* f) { /* mju_makeFrame: f[0:3] normal given, f[3:6
   normalize3(f + 3);
   cross3(f + 6, f, f + 3);
 }
-static void add_contact(nmo_data* d, const double* pos, const double* normal, double dist, int body, int geom) {
+static void add_contact2(nmo_data* d, const double* pos, const double* normal, double dist, int body1, int body, int geom) {
   if (d->ncon >= NMO_MAXCON) return;
   int c = d->ncon++;
   memcpy(d->con_pos[c], pos, 3 * sizeof(double));
@@ -262,7 +262,11 @@ static void add_contact(nmo_data* d, const double* pos, const double* normal, do
   make_frame(d->con_frame[c]);
   d->con_dist[c] = dist;
   d->con_body[c] = body;
+  d->con_body1[c] = body1;
   d->con_geom[c] = geom;
+}
+static void add_contact(nmo_data* d, const double* pos, const double* normal, double dist, int body, int geom) {
+  add_contact2(d, pos, normal, dist, 0, body, geom);
 }
 /* mjc_PlaneConvex for the floor (z = 0, normal +z, mjmodel.xml:32) against hull g of body b */
 static void plane_convex(nmo_data* d, int g) {
@@ -316,10 +320,236 @@ static void plane_convex(nmo_data* d, int g) {
     }
   }
 }
+
+/* ------------------------------------------------------------------ P5: convex-convex (tibia vs tibia) by MPR
+ * Restates libccd's ccdMPRPenetration (src/mpr.c, src/vec3.c) as MuJoCo 3.1.2 calls it from mjc_Convex:
+ * centre = geom frame origin (mesh COM), support = hull vertex of largest dot product, first_dir default,
+ * max_iterations = opt.mpr_iterations (50), mpr_tolerance = opt.mpr_tolerance (1e-6). One contact per pair. */
+#define CCD_EPS 2.220446049250313e-16
+#define MPR_TOL 1e-6
+#define MPR_MAXIT 50
+#define MPR_TIE 1e-7
+typedef struct { double v[3], v1[3], v2[3]; } sup_t;
+static int ccd_zero(double x) { return fabs(x) < CCD_EPS; }
+static int ccd_eq(double a, double b) {
+  double ab = fabs(a - b);
+  if (ab < CCD_EPS) return 1;
+  double fa = fabs(a), fb = fabs(b);
+  return ab < CCD_EPS * (fb > fa ? fb : fa);
+}
+static void hull_support(const nmo_data* d, int g, const double* dir, double* out) {
+  int b = nm_col_body[g], nvert = nm_col_nvert[g], vadr = nm_col_vadr[g];
+  double loc[3];
+  mulMatTVec3(loc, d->xmat[b], dir);
+  /* MPR queries supports along portal-face normals, where hull vertices tie by construction: break ties within
+   * MPR_TIE metres by lowest vertex index so that rounding noise cannot pick different vertices (libccd takes the
+   * strict maximum; MuJoCo hill-climbs - either way which of the tied vertices comes back is arbitrary upstream) */
+  int ibest = 0;
+  double best = -1e300;
+  for (int i = 0; i < nvert; i++) {
+    double v = dot3(loc, nm_hull_vert[vadr + i]);
+    if (v > best) best = v;
+  }
+  for (int i = 0; i < nvert; i++)
+    if (dot3(loc, nm_hull_vert[vadr + i]) >= best - MPR_TIE) { ibest = i; break; }
+  mulMatVec3(out, d->xmat[b], nm_hull_vert[vadr + ibest]);
+  for (int k = 0; k < 3; k++) out[k] += d->xpos[b][k];
+}
+static void mpr_support(const nmo_data* d, int g1, int g2, const double* dir, sup_t* s) {
+  double nd[3] = {-dir[0], -dir[1], -dir[2]};
+  hull_support(d, g1, dir, s->v1);
+  hull_support(d, g2, nd, s->v2);
+  for (int k = 0; k < 3; k++) s->v[k] = s->v1[k] - s->v2[k];
+}
+static void sub3(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static void ccd_normalize(double* v) { double s = 1.0 / sqrt(dot3(v, v)); v[0] *= s; v[1] *= s; v[2] *= s; }
+static void portal_dir(const sup_t* p, double* dir) {
+  double a[3], b[3];
+  sub3(a, p[2].v, p[1].v);
+  sub3(b, p[3].v, p[1].v);
+  cross3(dir, a, b);
+  ccd_normalize(dir);
+}
+static int portal_reach_tol(const sup_t* p, const sup_t* v4, const double* dir) {
+  double dv4 = dot3(v4->v, dir);
+  double d1 = dv4 - dot3(p[1].v, dir), d2 = dv4 - dot3(p[2].v, dir), d3 = dv4 - dot3(p[3].v, dir);
+  double m = d1 < d2 ? d1 : d2;
+  m = m < d3 ? m : d3;
+  return ccd_eq(m, MPR_TOL) || m < MPR_TOL;
+}
+static void expand_portal(sup_t* p, const sup_t* v4) {
+  double v4v0[3];
+  cross3(v4v0, v4->v, p[0].v);
+  if (dot3(p[1].v, v4v0) > 0) {
+    if (dot3(p[2].v, v4v0) > 0) p[1] = *v4; else p[3] = *v4;
+  } else {
+    if (dot3(p[3].v, v4v0) > 0) p[2] = *v4; else p[1] = *v4;
+  }
+}
+static double point_seg_dist2(const double* P, const double* x0, const double* b, double* wit) {
+  double dd[3], a[3];
+  sub3(dd, b, x0);
+  sub3(a, x0, P);
+  double t = -dot3(a, dd) / dot3(dd, dd);
+  if (t < 0 || ccd_zero(t)) { memcpy(wit, x0, 24); }
+  else if (t > 1 || ccd_eq(t, 1)) { memcpy(wit, b, 24); }
+  else { for (int k = 0; k < 3; k++) wit[k] = x0[k] + t * dd[k]; }
+  double e[3];
+  sub3(e, wit, P);
+  return dot3(e, e);
+}
+static double point_tri_dist2(const double* P, const double* x0, const double* B, const double* C, double* wit) {
+  double d1[3], d2[3], a[3];
+  sub3(d1, B, x0); sub3(d2, C, x0); sub3(a, x0, P);
+  double v = dot3(d1, d1), w = dot3(d2, d2), p = dot3(a, d1), q = dot3(a, d2), r = dot3(d1, d2);
+  double dd = w * v - r * r, s, t;
+  if (ccd_zero(dd)) { s = t = -1; }
+  else { s = (q * r - w * p) / dd; t = (-s * r - q) / w; }
+  if ((ccd_zero(s) || s > 0) && (ccd_eq(s, 1) || s < 1) && (ccd_zero(t) || t > 0) && (ccd_eq(t, 1) || t < 1) && (ccd_eq(t + s, 1) || t + s < 1)) {
+    for (int k = 0; k < 3; k++) wit[k] = x0[k] + s * d1[k] + t * d2[k];
+    double e[3];
+    sub3(e, wit, P);
+    return dot3(e, e);
+  }
+  double w2[3];
+  double dist = point_seg_dist2(P, x0, B, wit);
+  double dist2 = point_seg_dist2(P, x0, C, w2);
+  if (dist2 < dist) { dist = dist2; memcpy(wit, w2, 24); }
+  dist2 = point_seg_dist2(P, B, C, w2);
+  if (dist2 < dist) { dist = dist2; memcpy(wit, w2, 24); }
+  return dist;
+}
+/* returns 1 and fills depth/dir/pos when the hulls penetrate */
+static int mpr_penetration(const nmo_data* d, int g1, int g2, double* depth, double* dir_out, double* pos) {
+  sup_t p[4], v4;
+  double dir[3], va[3], vb[3], dot;
+  const double origin[3] = {0, 0, 0};
+  /* ---- discoverPortal */
+  for (int k = 0; k < 3; k++) {
+    double c1 = 0, c2 = 0;
+    for (int j = 0; j < 3; j++) {
+      c1 += d->xmat[nm_col_body[g1]][3 * k + j] * nm_col_center[g1][j];
+      c2 += d->xmat[nm_col_body[g2]][3 * k + j] * nm_col_center[g2][j];
+    }
+    p[0].v1[k] = c1 + d->xpos[nm_col_body[g1]][k];
+    p[0].v2[k] = c2 + d->xpos[nm_col_body[g2]][k];
+    p[0].v[k] = p[0].v1[k] - p[0].v2[k];
+  }
+  if (ccd_eq(p[0].v[0], 0) && ccd_eq(p[0].v[1], 0) && ccd_eq(p[0].v[2], 0)) p[0].v[0] += CCD_EPS * 10;
+  for (int k = 0; k < 3; k++) dir[k] = -p[0].v[k];
+  ccd_normalize(dir);
+  mpr_support(d, g1, g2, dir, &p[1]);
+  dot = dot3(p[1].v, dir);
+  if (ccd_zero(dot) || dot < 0) return 0;
+  cross3(dir, p[0].v, p[1].v);
+  if (ccd_zero(dot3(dir, dir))) {
+    if (ccd_eq(p[1].v[0], 0) && ccd_eq(p[1].v[1], 0) && ccd_eq(p[1].v[2], 0)) return 0; /* touching: dir undefined -> MuJoCo drops it */
+    /* origin on the v0-v1 segment: findPenetrSegment */
+    *depth = sqrt(dot3(p[1].v, p[1].v));
+    memcpy(dir_out, p[1].v, 24);
+    ccd_normalize(dir_out);
+    for (int k = 0; k < 3; k++) pos[k] = 0.5 * (p[1].v1[k] + p[1].v2[k]);
+    return 1;
+  }
+  ccd_normalize(dir);
+  mpr_support(d, g1, g2, dir, &p[2]);
+  dot = dot3(p[2].v, dir);
+  if (ccd_zero(dot) || dot < 0) return 0;
+  sub3(va, p[1].v, p[0].v);
+  sub3(vb, p[2].v, p[0].v);
+  cross3(dir, va, vb);
+  ccd_normalize(dir);
+  if (dot3(dir, p[0].v) > 0) {
+    sup_t t = p[1]; p[1] = p[2]; p[2] = t;
+    for (int k = 0; k < 3; k++) dir[k] = -dir[k];
+  }
+  for (int size = 3; size < 4;) {
+    mpr_support(d, g1, g2, dir, &p[3]);
+    dot = dot3(p[3].v, dir);
+    if (ccd_zero(dot) || dot < 0) return 0;
+    int cont = 0;
+    cross3(va, p[1].v, p[3].v);
+    dot = dot3(va, p[0].v);
+    if (dot < 0 && !ccd_zero(dot)) { p[2] = p[3]; cont = 1; }
+    if (!cont) {
+      cross3(va, p[3].v, p[2].v);
+      dot = dot3(va, p[0].v);
+      if (dot < 0 && !ccd_zero(dot)) { p[1] = p[3]; cont = 1; }
+    }
+    if (cont) {
+      sub3(va, p[1].v, p[0].v);
+      sub3(vb, p[2].v, p[0].v);
+      cross3(dir, va, vb);
+      ccd_normalize(dir);
+    } else size = 4;
+  }
+  /* ---- refinePortal */
+  for (int guard = 0; guard < 1000; guard++) {
+    portal_dir(p, dir);
+    dot = dot3(dir, p[1].v);
+    if (ccd_zero(dot) || dot > 0) break; /* portal encapsules the origin */
+    mpr_support(d, g1, g2, dir, &v4);
+    dot = dot3(v4.v, dir);
+    if (!(ccd_zero(dot) || dot > 0) || portal_reach_tol(p, &v4, dir)) return 0;
+    expand_portal(p, &v4);
+    if (guard == 999) return 0;
+  }
+  /* ---- findPenetr */
+  for (int it = 0;; it++) {
+    portal_dir(p, dir);
+    mpr_support(d, g1, g2, dir, &v4);
+    if (portal_reach_tol(p, &v4, dir) || it > MPR_MAXIT) {
+      double pd[3];
+      *depth = sqrt(point_tri_dist2(origin, p[1].v, p[2].v, p[3].v, pd));
+      if (ccd_zero(pd[0]) && ccd_zero(pd[1]) && ccd_zero(pd[2])) memcpy(pd, dir, 24);
+      ccd_normalize(pd);
+      memcpy(dir_out, pd, 24);
+      /* findPos: barycentric coordinates of the origin in the portal tetrahedron */
+      double b[4], t[3], sum;
+      portal_dir(p, dir);
+      cross3(t, p[1].v, p[2].v); b[0] = dot3(t, p[3].v);
+      cross3(t, p[3].v, p[2].v); b[1] = dot3(t, p[0].v);
+      cross3(t, p[0].v, p[1].v); b[2] = dot3(t, p[3].v);
+      cross3(t, p[2].v, p[1].v); b[3] = dot3(t, p[0].v);
+      sum = b[0] + b[1] + b[2] + b[3];
+      if (ccd_zero(sum) || sum < 0) {
+        b[0] = 0;
+        cross3(t, p[2].v, p[3].v); b[1] = dot3(t, dir);
+        cross3(t, p[3].v, p[1].v); b[2] = dot3(t, dir);
+        cross3(t, p[1].v, p[2].v); b[3] = dot3(t, dir);
+        sum = b[1] + b[2] + b[3];
+      }
+      double inv = 1.0 / sum;
+      for (int k = 0; k < 3; k++) {
+        double p1 = 0, p2 = 0;
+        for (int i = 0; i < 4; i++) { p1 += b[i] * p[i].v1[k]; p2 += b[i] * p[i].v2[k]; }
+        pos[k] = 0.5 * (p1 * inv + p2 * inv);
+      }
+      return 1;
+    }
+    expand_portal(p, &v4);
+  }
+}
+static void convex_pairs(nmo_data* d) {
+  for (int g1 = 1; g1 < NM_NCOL; g1++)
+    for (int g2 = g1 + 1; g2 < NM_NCOL; g2++) {
+      int b1 = nm_col_body[g1], b2 = nm_col_body[g2];
+      double c1[3], c2[3], dd[3];
+      mulMatVec3(c1, d->xmat[b1], nm_col_center[g1]);
+      mulMatVec3(c2, d->xmat[b2], nm_col_center[g2]);
+      for (int k = 0; k < 3; k++) dd[k] = (c1[k] + d->xpos[b1][k]) - (c2[k] + d->xpos[b2][k]);
+      double bound = nm_col_rbound[g1] + nm_col_rbound[g2];
+      if (dot3(dd, dd) > bound * bound) continue; /* mj_filterSphere */
+      double depth, dir[3], pos[3];
+      if (!mpr_penetration(d, g1, g2, &depth, dir, pos)) continue;
+      if (depth <= 0) continue; /* dist >= includemargin: excluded */
+      add_contact2(d, pos, dir, -depth, b1, b2, g2);
+    }
+}
 static void collision(nmo_data* d) {
   d->ncon = 0;
   for (int g = 0; g < NM_NCOL; g++) plane_convex(d, g);
-  (void)g_collide_self; /* tibia-tibia convex pairs: see DESIGN.md (not generated in this round) */
+  if (g_collide_self) convex_pairs(d); /* tibia-tibia pairs (contype 2 / conaffinity 3, mjmodel.xml:47...) after the floor pairs */
 }
 
 /* ------------------------------------------------------------------ P6: mj_makeConstraint (+ impedance, diagApprox) */
@@ -351,11 +581,17 @@ static void make_constraint(nmo_data* d, nmo_scratch* s) {
   for (int c = 0; c < d->ncon; c++) {
     double jp[3][NV], jf[3][NV];
     jac_point(d, jp, d->con_body[c], d->con_pos[c]);
+    if (d->con_body1[c] > 0) { /* mj_jacDifPair: J(body2) - J(body1) */
+      double j1[3][NV];
+      jac_point(d, j1, d->con_body1[c], d->con_pos[c]);
+      for (int r = 0; r < 3; r++)
+        for (int i = 0; i < NV; i++) jp[r][i] -= j1[r][i];
+    }
     const double* fr = d->con_frame[c];
     for (int r = 0; r < 3; r++)
       for (int i = 0; i < NV; i++) jf[r][i] = fr[3 * r] * jp[0][i] + fr[3 * r + 1] * jp[1][i] + fr[3 * r + 2] * jp[2][i];
     /* pyramidal cone, condim 3: rows n + mu t1, n - mu t1, n + mu t2, n - mu t2 (mj_instantiateContact) */
-    double tran = nm_body_invweight0[d->con_body[c]][0]; /* + world (0) */
+    double tran = nm_body_invweight0[d->con_body[c]][0] + nm_body_invweight0[d->con_body1[c]][0]; /* world = 0 */
     double imp = impedance(d->con_dist[c]);
     double dA = tran + mu * mu * tran; /* mj_diagApprox, pyramidal */
     double R = (1 - imp) * dA / imp;
@@ -575,13 +811,14 @@ static void sensor_touch(nmo_data* d) {
     for (int k = 0; k < 3; k++) sp[k] += d->xpos[b][k];
     double sum = 0;
     for (int c = 0; c < d->ncon; c++) {
-      if (d->con_body[c] != b) continue; /* body1 is always the world here */
+      if (d->con_body[c] != b && d->con_body1[c] != b) continue;
       const double* f = d->efc_force + 4 * c;
       double normal = f[0] + f[1] + f[2] + f[3]; /* mj_contactForce, pyramidal: normal = sum of edge forces */
       if (normal <= 0) continue;
       double ray[3] = {d->con_frame[c][0] * normal, d->con_frame[c][1] * normal, d->con_frame[c][2] * normal};
       normalize3(ray);
-      for (int k = 0; k < 3; k++) ray[k] = -ray[k]; /* sensor body is geom2's body */
+      if (d->con_body[c] == b)
+        for (int k = 0; k < 3; k++) ray[k] = -ray[k]; /* flip when the sensor is on body2 */
       if (ray_sphere(sp, nm_sens_radius[sidx], d->con_pos[c], ray) >= 0) sum += normal;
     }
     d->sensordata[sidx] = sum;

@@ -37,7 +37,7 @@ class NmoData(C.Structure):
         ("qfrc_constraint", d_ * NV), ("qacc", d_ * NV),
         ("ncon", C.c_int32), ("nefc", C.c_int32),
         ("con_pos", d_ * 3 * MAXCON), ("con_frame", d_ * 9 * MAXCON), ("con_dist", d_ * MAXCON),
-        ("con_body", C.c_int32 * MAXCON), ("con_geom", C.c_int32 * MAXCON),
+        ("con_body", C.c_int32 * MAXCON), ("con_body1", C.c_int32 * MAXCON), ("con_geom", C.c_int32 * MAXCON),
         ("efc_force", d_ * MAXEFC),
         ("sensordata", d_ * NSENS),
         ("solver_niter", C.c_int32), ("noslip_niter", C.c_int32), ("nwarning", C.c_int32), ("pad", C.c_int32),
@@ -81,6 +81,7 @@ def lib():
         L.nmo_reset_data.argtypes = [P(NmoData)]
         L.nmo_forward.argtypes = [P(NmoData), P(NmoScratch)]
         L.nmo_step.argtypes = [P(NmoData), P(NmoScratch), C.c_int]
+        L.nmo_set_collide_self.argtypes = [C.c_int]
         L.nmo_env_create.restype = C.c_void_p
         L.nmo_env_create.argtypes = [C.c_int, C.c_uint64, C.c_int64, C.c_int]
         L.nmo_env_destroy.argtypes = [C.c_void_p]

@@ -7,6 +7,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = NightmareV3Config(); cfg.env.num_envs = N
 acts = (torch.rand(16, N, 18, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda()
 env = NightmareV3Env(cfg, seed=0); env.reset()
+mask = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+env._L.nm_set_ablation(env._h, mask)
 for i in range(300): env.step(acts[i % 16])
 res = []
 for rep in range(3):
@@ -14,4 +16,4 @@ for rep in range(3):
     for i in range(200): env.step(acts[i % 16])
     ms, n = env.profile(False)
     res.append(ms / n * 1e3)
-print(f"N={N} step kernel avg us: " + " ".join(f"{r:.1f}" for r in res) + f"  -> {N / min(res):.2f} M env-steps/s (kernel only)")
+print(f"mask={mask} N={N} step kernel avg us: " + " ".join(f"{r:.1f}" for r in res) + f"  -> {N / min(res):.2f} M env-steps/s (kernel only)")

@@ -55,7 +55,7 @@ template <class real> struct Emu : EmuBase {
     std::vector<real> cu, dbgr((size_t)N * nm::kDbgN, 0), ssum(8, 0);
     if (cmd_u) { cu.resize((size_t)N * 4); for (size_t i = 0; i < cu.size(); i++) cu[i] = (real)cmd_u[i]; }
     int scnt[4] = {0, 0, 0, 0};
-    nm::Args<real> A;
+    nm::Args<real> A{};
     A.N = N; A.seed = seed; A.env_offset = off;
     A.qpos = qpos.data(); A.qvel = qvel.data(); A.qwarm = qwarm.data(); A.dofpos = dofpos.data(); A.dofvel = dofvel.data();
     A.act = act.data(); A.cmd = cmd.data(); A.epsum = epsum.data(); A.eplen = ep.data(); A.rngctr = ctr.data();
