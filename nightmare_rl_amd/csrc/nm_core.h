@@ -594,7 +594,7 @@ template <class real> NM_FN void hull_support(const Sh<real>& sh, const Model<re
   matvec3(t, R, v);
   out[0] = p[0] + t[0]; out[1] = p[1] + t[1]; out[2] = p[2] + t[2];
 }
-template <class real> NM_FN void mpr_support(const Sh<real>& sh, const Model<real>& M, int g1, int g2, const real* dir, Sup<real>& s) {
+template <class real> NM_COLD void mpr_support(const Sh<real>& sh, const Model<real>& M, int g1, int g2, const real* dir, Sup<real>& s) {
   real nd[3] = {-dir[0], -dir[1], -dir[2]};
   hull_support(sh, M, g1, dir, s.v1);
   hull_support(sh, M, g2, nd, s.v2);
@@ -653,7 +653,7 @@ template <class real> NM_FN real point_tri_dist2(const real* x0, const real* B, 
   return dist;
 }
 // true and (depth, dir from geom1 to geom2, pos) when the two hulls penetrate
-template <class real> NM_FN bool mpr_penetration(const Sh<real>& sh, const Model<real>& M, int g1, int g2, real* depth, real* dir_out, real* pos) {
+template <class real> NM_COLD bool mpr_penetration(const Sh<real>& sh, const Model<real>& M, int g1, int g2, real* depth, real* dir_out, real* pos) {
   Sup<real> p[4], v4;
   real dir[3], va[3], vb[3], dot;
   {  // discoverPortal: v0 = centre1 - centre2
@@ -922,7 +922,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
 
 // =========================================================================================  stage C
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
-template <class real, bool PAIR> NM_FN void stage_constraint_impl(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
+template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const int ncon = uniform(sh.ncon), nefc = 4 * ncon;
@@ -1255,9 +1255,12 @@ template <class real, bool PAIR> NM_FN void stage_constraint_impl(Sh<real>& sh, 
   wave_sync();
 }
 
+template <class real> NM_COLD void stage_constraint_pairs(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
+  stage_constraint_body<real, true>(sh, M, last, nosweep);
+}
 template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep = false) {
-  if (uniform(sh.anypair) != 0) stage_constraint_impl<real, true>(sh, M, last, nosweep);
-  else stage_constraint_impl<real, false>(sh, M, last, nosweep);
+  if (uniform(sh.anypair) != 0) stage_constraint_pairs<real>(sh, M, last, nosweep);
+  else stage_constraint_body<real, false>(sh, M, last, nosweep);
 }
 
 // =========================================================================================  stage D

@@ -19,6 +19,7 @@
 // =====================================================================================  DEVICE (gfx950)
 #include <hip/hip_runtime.h>
 #define NM_FN __device__ __forceinline__
+#define NM_COLD __device__ __noinline__   /* rarely executed paths: keep them out of the hot instruction stream */
 namespace simt {
 template <class T> using V = T;
 using VB = bool;
@@ -131,6 +132,7 @@ NM_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 #include <cmath>
 #include <cstring>
 #define NM_FN inline
+#define NM_COLD inline
 namespace simt {
 template <class T> struct V {
   T v[NM_WAVE];
