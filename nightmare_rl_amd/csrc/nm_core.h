@@ -22,6 +22,8 @@
 // All inter-stage traffic goes through ~6.6 KB of LDS per wave; HBM is touched once per env-step
 // (state in, state + obs out).
 #pragma once
+#include <stddef.h>
+
 #include "simt.h"
 
 namespace nm {
@@ -73,6 +75,7 @@ template <class real> struct Args {
   real *dofpos, *dofvel, *act, *cmd, *epsum;
   int64_t* eplen;
   uint32_t* rngctr;
+  int* hullcache;        // [N,8] warm start of the support-vertex search (any value in range is valid)
   // inputs
   const float* actions;  // [N,18]
   const real* cmd_u;     // [N,4] or null
@@ -99,7 +102,6 @@ template <class real> struct Sh {
   real qas[24], qfs[24], qfc[24];
   real cpos[kMaxCon * 3], cdist[kMaxCon], cnrm[kMaxCon * 3];
   int cleg[kMaxCon], cleg1[kMaxCon];   // leg of body2 (-1 = base), leg of body1 (-1 = world/floor)
-  real jrow[kMaxRow * kJRow];
   real sens[16], cvb[6];
   real mbb[36], sc[36];           // base block of M and its Schur complement (upper triangles)
   real legtmp[kNLEG * 66];        // per-leg staging between the forward and backward chain passes: 3 x (S6 I10 f6)
@@ -108,7 +110,17 @@ template <class real> struct Sh {
   real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
+  int nfallback;
+  int hcache[8];                  // support vertex of each colliding mesh found last time (warm start of the hull search)
 };
+
+// LDS of one wavefront: G env images (the leg-lane stages run all G envs at once, lanes 8g..8g+5 = legs of env g; collision,
+// constraints and the env epilogue take the envs one after the other on all 64 lanes) + one shared row buffer.
+template <class real, int G> struct ShW {
+  Sh<real> e[G];
+  real jrow[kMaxRow * kJRow];
+};
+#define NM_OFS(field) ((int)(offsetof(Sh<real>, field) / sizeof(real)))
 
 // ----------------------------------------------------------------------------------------- small algebra
 template <class A, class B, class C> NM_FN void cross3(A* r, const B* a, const C* b) {
@@ -193,20 +205,21 @@ template <class X, class Y> NM_FN void ldl3_solve(X* x, const X* f, const Y* y) 
   x[2] = y2 * f[3] - f[0] * x1 - f[1] * x0;
   x[1] = x1; x[0] = x0;
 }
-// LDL' of a symmetric 6x6 given by its upper triangle in row-major S[36] (wave-uniform, may live in LDS): L strictly lower (15, row-major packed), Dinv(6)
-template <class real> NM_FN void ldl6(const real* S, real* L, real* Dinv) {
-  real Lf[36], D[6];
+// LDL' of a symmetric 6x6 given by its upper triangle through the accessor S(row, col), row <= col:
+// L strictly lower (15, row-major packed), Dinv(6). X = real (wave-uniform) or V<real> (one matrix per lane group).
+template <class X, class real, class Acc> NM_FN void ldl6(Acc S, X* L, X* Dinv, real one) {
+  X Lf[36], D[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
-    real d = S[7 * j];
+    X d = S(j, j);
 #pragma unroll
     for (int k = 0; k < j; k++) d = d - Lf[6 * j + k] * Lf[6 * j + k] * D[k];
     D[j] = d;
-    real di = real(1) / d;
+    X di = X(one) / d;
     Dinv[j] = di;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
-      real s = S[6 * j + i];  // upper triangle only
+      X s = S(j, i);
 #pragma unroll
       for (int k = 0; k < j; k++) s = s - Lf[6 * i + k] * Lf[6 * j + k] * D[k];
       Lf[6 * i + j] = s * di;
@@ -218,8 +231,8 @@ template <class real> NM_FN void ldl6(const real* S, real* L, real* Dinv) {
 #pragma unroll
     for (int j = 0; j < i; j++) L[n++] = Lf[6 * i + j];
 }
-// x <- (L D L')^-1 x ; L, Dinv wave-uniform (LDS), x per lane or uniform
-template <class X, class real> NM_FN void ldl6_solve(const real* L, const real* Dinv, X* x) {
+// x <- (L D L')^-1 x
+template <class LT, class X> NM_FN void ldl6_solve(const LT* L, const LT* Dinv, X* x) {
   int n = 0;
 #pragma unroll
   for (int i = 1; i < 6; i++)
@@ -245,62 +258,84 @@ NM_FN uint32_t rand_u24_bits(uint64_t seed, uint64_t genv, uint32_t ctr) {
 }
 
 // =========================================================================================  stage A
-// Everything "smooth": kinematics, inertia blocks + both factorisations, bias, servo forces, qacc_smooth.
-// Forward pass down each leg chain (one leg per lane) parks per-link results in the leg's LDS slots; the
-// backward pass picks them up again. That keeps the live register set small enough for 4 waves/SIMD.
+// Everything "smooth": kinematics, inertia blocks + both factorisations, bias, servo forces, qacc_smooth - for all G
+// envs of the wave at once. Lanes 8g..8g+5 are the six legs of env g; what is "per env" (base frame, base inertia,
+// Schur complement ...) is computed redundantly by the 8 lanes of the group, so no cross-lane broadcast is needed and
+// sums over legs are three DPP adds (gsum8). The forward pass down each leg chain parks per-link results in the
+// leg's LDS slots; the backward pass picks them up again (keeps the live register set small).
 constexpr int kLinkTmp = 22;  // per link in LDS: S(6) I10(10) f(6)
 
-template <class real> NM_FN real legsum(const V<real>& x, const VB& isleg) {  // sum over the six leg lanes -> uniform
-  return wsum8<real>(sel(isleg, x, V<real>(real(0))));
+template <class real, int G> struct Grp {  // lane -> (env slot, leg) mapping of the leg-lane stages
+  V<int> sub, leg, eo;
+  VB gact, isleg, lead;
+  NM_FN Grp() {
+    const V<int> lane = lane_id();
+    sub = lane & 7;
+    leg = vmin(sub, V<int>(5));
+    V<int> g = lane >> 3;
+    gact = g < G;
+    isleg = gact & (sub < 6);
+    lead = gact & (sub == 0);
+    eo = vmin(g, V<int>(G - 1)) * (int)(sizeof(Sh<real>) / sizeof(real));
+  }
+};
+template <class real> NM_FN V<real> legsum(const V<real>& x, const VB& isleg) {  // sum over the legs of the lane's env
+  return gsum8(sel(isleg, x, V<real>(real(0))));
 }
 
-template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M, bool last) {
+template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Model<real>& M, bool last) {
   typedef V<real> vr;
-  const V<int> lane = lane_id();
-  const V<int> leg = lane % 6;
-  const VB isleg = lane < 6;
+  real* lds = reinterpret_cast<real*>(&w.e[0]);
+  const Grp<real, G> gp;
+  const V<int> leg = gp.leg, eo = gp.eo;
+  const VB isleg = gp.isleg, lead = gp.lead;
+#define LDG(field, i) ldsv(lds, eo + (NM_OFS(field) + (i)))
+#define STG(field, i, val) stsv(lds, eo + (NM_OFS(field) + (i)), val, lead)
+#define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
+#define STL(field, idx, val) stsv(lds, eo + (idx) + NM_OFS(field), val, isleg)
   const V<int> slot = leg * (3 * kLinkTmp);
 
-  // ---- base frame (uniform)
-  real Rb[9];
+  // ---- base frame (per env)
+  vr Rb[9];
   {
-    real qw = sh.qpos[3], qx = sh.qpos[4], qy = sh.qpos[5], qz = sh.qpos[6];
-    real q00 = qw * qw, q01 = qw * qx, q02 = qw * qy, q03 = qw * qz, q11 = qx * qx, q12 = qx * qy, q13 = qx * qz, q22 = qy * qy,
-         q23 = qy * qz, q33 = qz * qz;
+    vr qw = LDG(qpos, 3), qx = LDG(qpos, 4), qy = LDG(qpos, 5), qz = LDG(qpos, 6);
+    vr q00 = qw * qw, q01 = qw * qx, q02 = qw * qy, q03 = qw * qz, q11 = qx * qx, q12 = qx * qy, q13 = qx * qz, q22 = qy * qy,
+       q23 = qy * qz, q33 = qz * qz;
     Rb[0] = q00 + q11 - q22 - q33; Rb[4] = q00 - q11 + q22 - q33; Rb[8] = q00 - q11 - q22 + q33;
     Rb[1] = real(2) * (q12 - q03); Rb[2] = real(2) * (q13 + q02); Rb[3] = real(2) * (q12 + q03);
     Rb[5] = real(2) * (q23 - q01); Rb[6] = real(2) * (q13 - q02); Rb[7] = real(2) * (q23 + q01);
   }
-  real vb[6], ab[6];  // base spatial velocity [w_world; v_origin] and bias acceleration (-gravity + v x w)
+  vr vb[6], ab[6];  // base spatial velocity [w_world; v_origin] and bias acceleration (-gravity + v x w)
   {
-    real wl[3] = {sh.qvel[3], sh.qvel[4], sh.qvel[5]};
+    vr wl[3] = {LDG(qvel, 3), LDG(qvel, 4), LDG(qvel, 5)};
     matvec3(vb, Rb, wl);
-    vb[3] = sh.qvel[0]; vb[4] = sh.qvel[1]; vb[5] = sh.qvel[2];
-    real t[3];
+    vb[3] = LDG(qvel, 0); vb[4] = LDG(qvel, 1); vb[5] = LDG(qvel, 2);
+    vr t[3];
     cross3(t, vb + 3, vb);
-    ab[0] = ab[1] = ab[2] = real(0);
+    ab[0] = ab[1] = ab[2] = vr(real(0));
     ab[3] = t[0]; ab[4] = t[1]; ab[5] = t[2] + M.grav;
   }
 #pragma unroll
-  for (int j = 0; j < 9; j++) { sh.colR[j] = Rb[j]; sh.Rb[j] = Rb[j]; }
-  sh.colp[0] = sh.colp[1] = sh.colp[2] = real(0);
+  for (int j = 0; j < 9; j++) { STG(colR, j, Rb[j]); STG(Rb, j, Rb[j]); }
 #pragma unroll
-  for (int j = 0; j < 6; j++) sh.wv[j] = vb[j];
+  for (int j = 0; j < 3; j++) STG(colp, j, vr(real(0)));
+#pragma unroll
+  for (int j = 0; j < 6; j++) STG(wv, j, vb[j]);
 
   // ---- forward pass down the chain: pose, motion vector, spatial inertia, velocity, bias acceleration, body force
   vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
   {
     vr Rp[9], pp[3], vpar[6], apar[6];
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rp[k] = vr(Rb[k]);
+    for (int k = 0; k < 9; k++) Rp[k] = Rb[k];
     pp[0] = pp[1] = pp[2] = vr(real(0));
 #pragma unroll
-    for (int k = 0; k < 6; k++) { vpar[k] = vr(vb[k]); apar[k] = vr(ab[k]); }
+    for (int k = 0; k < 6; k++) { vpar[k] = vb[k]; apar[k] = ab[k]; }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       sched_fence();
       const V<int> cb = leg * kLegN + k * kLinkN;
-      vr q = ldsv(sh.qpos, leg * 3 + (7 + k)), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
+      vr q = LDL(qpos, leg * 3 + (7 + k)), qd = LDL(qvel, leg * 3 + (6 + k));
       vr pos[3], t3[3], aw[3], R[9];
       {
         vr bpos[3] = {gldv(M.legc, cb), gldv(M.legc, cb + 1), gldv(M.legc, cb + 2)};
@@ -329,14 +364,14 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
       // publish joint anchor/axis (row stage) and, for the tibia, the collision frame
 #pragma unroll
       for (int j = 0; j < 3; j++) {
-        stsv(sh.anc, leg * 9 + (3 * k + j), pos[j], isleg);
-        stsv(sh.axs, leg * 9 + (3 * k + j), aw[j], isleg);
+        STL(anc, leg * 9 + (3 * k + j), pos[j]);
+        STL(axs, leg * 9 + (3 * k + j), aw[j]);
       }
       if (k == 2) {
 #pragma unroll
-        for (int j = 0; j < 9; j++) stsv(sh.colR, (leg + 1) * 9 + j, R[j], isleg);
+        for (int j = 0; j < 9; j++) STL(colR, (leg + 1) * 9 + j, R[j]);
 #pragma unroll
-        for (int j = 0; j < 3; j++) stsv(sh.colp, (leg + 1) * 3 + j, pos[j], isleg);
+        for (int j = 0; j < 3; j++) STL(colp, (leg + 1) * 3 + j, pos[j]);
       }
       sched_fence();
       vr S[6], I10[10];
@@ -372,11 +407,11 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
       }
       const V<int> o = slot + k * kLinkTmp;
 #pragma unroll
-      for (int j = 0; j < 6; j++) stsv(sh.legtmp, o + j, S[j], isleg);
+      for (int j = 0; j < 6; j++) STL(legtmp, o + j, S[j]);
 #pragma unroll
-      for (int j = 0; j < 10; j++) stsv(sh.legtmp, o + (6 + j), I10[j], isleg);
+      for (int j = 0; j < 10; j++) STL(legtmp, o + (6 + j), I10[j]);
 #pragma unroll
-      for (int j = 0; j < 6; j++) stsv(sh.legtmp, o + (16 + j), f[j], isleg);
+      for (int j = 0; j < 6; j++) STL(legtmp, o + (16 + j), f[j]);
 #pragma unroll
       for (int j = 0; j < 9; j++) Rp[j] = R[j];
       pp[0] = pos[0]; pp[1] = pos[1]; pp[2] = pos[2];
@@ -396,11 +431,11 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
     const V<int> o = slot + k * kLinkTmp;
     vr S[6], F[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) S[j] = ldsv(sh.legtmp, o + j);
+    for (int j = 0; j < 6; j++) S[j] = LDL(legtmp, o + j);
 #pragma unroll
-    for (int j = 0; j < 10; j++) Ic[j] += ldsv(sh.legtmp, o + (6 + j));
+    for (int j = 0; j < 10; j++) Ic[j] += LDL(legtmp, o + (6 + j));
 #pragma unroll
-    for (int j = 0; j < 6; j++) fs[j] += ldsv(sh.legtmp, o + (16 + j));
+    for (int j = 0; j < 6; j++) fs[j] += LDL(legtmp, o + (16 + j));
     cl[k] = dot6<vr>(S, fs);
     inert_mul(F, Ic, S);
     Mlb[k][0] = F[3]; Mlb[k][1] = F[4]; Mlb[k][2] = F[5];
@@ -412,28 +447,29 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
     for (int jj = 0; jj < k; jj++) {  // ancestors within the leg
       vr Sj[6];
 #pragma unroll
-      for (int j = 0; j < 6; j++) Sj[j] = ldsv(sh.legtmp, slot + (jj * kLinkTmp + j));
+      for (int j = 0; j < 6; j++) Sj[j] = LDL(legtmp, slot + (jj * kLinkTmp + j));
       Ml[(jj == 0) ? k : 4] = dot6<vr>(Sj, F);  // (0,k) -> index k ; (1,2) -> index 4
     }
   }
   sched_fence();
   // ---- base: own inertia/force + legs
-  real Icb[10], cbias[6];
+  vr Icb[10], cbias[6];
   {
-    real Ib10[10];
-    real ipos[3] = {M.basec[0], M.basec[1], M.basec[2]}, Ibody[6] = {M.basec[3], M.basec[4], M.basec[5], M.basec[6], M.basec[7], M.basec[8]};
-    real d[3];
+    vr Ib10[10];
+    vr ipos[3] = {vr(M.basec[0]), vr(M.basec[1]), vr(M.basec[2])};
+    vr Ibody[6] = {vr(M.basec[3]), vr(M.basec[4]), vr(M.basec[5]), vr(M.basec[6]), vr(M.basec[7]), vr(M.basec[8])};
+    vr d[3];
     matvec3(d, Rb, ipos);
-    spatial_inertia(Ib10, Rb, Ibody, d, M.basec[9], real(0));
+    spatial_inertia(Ib10, Rb, Ibody, d, vr(M.basec[9]), real(0));
     if (last) {  // subtree COM (relative to the base origin) -> cvel[1] as MuJoCo reports it (about the COM)
-      real cr[3], t[3];
+      vr cr[3], t[3];
 #pragma unroll
       for (int j = 0; j < 3; j++) cr[j] = (M.basec[9] * d[j] + legsum<real>(mcom[j], isleg)) / M.total_mass;
       cross3(t, vb, cr);
-      sh.cvb[0] = vb[0]; sh.cvb[1] = vb[1]; sh.cvb[2] = vb[2];
-      sh.cvb[3] = vb[3] + t[0]; sh.cvb[4] = vb[4] + t[1]; sh.cvb[5] = vb[5] + t[2];
+#pragma unroll
+      for (int j = 0; j < 3; j++) { STG(cvb, j, vb[j]); STG(cvb, 3 + j, vb[3 + j] + t[j]); }
     }
-    real fb[6], t6[6], u6[6], w6[6];
+    vr fb[6], t6[6], u6[6], w6[6];
     inert_mul(t6, Ib10, ab);
     inert_mul(u6, Ib10, vb);
     cross_force(w6, vb, u6);
@@ -446,19 +482,19 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
     for (int j = 0; j < 10; j++) Icb[j] = Ib10[j] + legsum<real>(Ic[j], isleg);
   }
   // base block of M from the composite inertia (I6, h = m*d, m) about the base origin, dofs (x y z | body axes a_j = Rb[:,j]):
-  //   trans-trans m*1 ; trans-rot column j = a_j x h ; rot-rot Rb' I Rb
-  {  // written to LDS (wave-uniform values do not deserve 36 VGPRs across both factorisation passes)
-    real* Mbb = sh.mbb;
+  //   trans-trans m*1 ; trans-rot column j = a_j x h ; rot-rot Rb' I Rb      (upper triangle, parked in LDS)
+  {
 #pragma unroll
-    for (int i = 0; i < 36; i++) Mbb[i] = real(0);
-    Mbb[0] = Mbb[7] = Mbb[14] = Icb[9];
-    real T[9];
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+      for (int j = i; j < 3; j++) STG(mbb, 6 * i + j, (i == j) ? Icb[9] : vr(real(0)));
+    vr T[9];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      real a[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, c[3];
+      vr a[3] = {Rb[j], Rb[3 + j], Rb[6 + j]}, c[3];
       cross3(c, a, Icb + 6);
 #pragma unroll
-      for (int i = 0; i < 3; i++) { Mbb[6 * i + 3 + j] = c[i]; }
+      for (int i = 0; i < 3; i++) STG(mbb, 6 * i + 3 + j, c[i]);
       T[j] = Icb[0] * a[0] + Icb[3] * a[1] + Icb[4] * a[2];       // (I a_j), stored column-wise: T[3*r + j]
       T[3 + j] = Icb[3] * a[0] + Icb[1] * a[1] + Icb[5] * a[2];
       T[6 + j] = Icb[4] * a[0] + Icb[5] * a[1] + Icb[2] * a[2];
@@ -466,7 +502,7 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-      for (int j = i; j < 3; j++) Mbb[6 * (3 + i) + 3 + j] = Rb[i] * T[j] + Rb[3 + i] * T[3 + j] + Rb[6 + i] * T[6 + j];
+      for (int j = i; j < 3; j++) STG(mbb, 6 * (3 + i) + 3 + j, Rb[i] * T[j] + Rb[3 + i] * T[3 + j] + Rb[6 + i] * T[6 + j]);
   }
   wave_sync();
 
@@ -485,64 +521,65 @@ template <class real> NM_FN void stage_smooth(Sh<real>& sh, const Model<real>& M
       ldl3_solve(r3, Mi, col);
       W[0][j] = r3[0]; W[1][j] = r3[1]; W[2][j] = r3[2];
     }
-    real* shMinv = pass ? sh.MinvH : sh.Minv;
-    real* shW = pass ? sh.WH : sh.W;
-    real* shL = pass ? sh.LbH : sh.Lb;
-    real* shD = pass ? sh.DbiH : sh.Dbi;
+    const int oMinv = pass ? NM_OFS(MinvH) : NM_OFS(Minv), oW = pass ? NM_OFS(WH) : NM_OFS(W);
+    const int oL = pass ? NM_OFS(LbH) : NM_OFS(Lb), oD = pass ? NM_OFS(DbiH) : NM_OFS(Dbi);
 #pragma unroll
-    for (int j = 0; j < 6; j++) stsv(shMinv, leg * 6 + j, Mi[j], isleg);
+    for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 6 + (oMinv + j), Mi[j], isleg);
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
-      for (int j = 0; j < 6; j++) stsv(shW, leg * 18 + (6 * k + j), W[k][j], isleg);
+      for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 18 + (oW + 6 * k + j), W[k][j], isleg);
     // Schur complement of the leg blocks (upper triangle, row-major in LDS)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
       for (int j = i; j < 6; j++) {
         vr cij = Mlb[0][i] * W[0][j] + Mlb[1][i] * W[1][j] + Mlb[2][i] * W[2][j];
-        sh.sc[6 * i + j] = sh.mbb[6 * i + j] - legsum<real>(cij, isleg);
+        STG(sc, 6 * i + j, LDG(mbb, 6 * i + j) - legsum<real>(cij, isleg));
       }
     wave_sync();
-    real L[15], Di[6];
-    ldl6(sh.sc, L, Di);
+    vr L[15], Di[6];
+    ldl6([&](int r, int c) { return LDG(sc, 6 * r + c); }, L, Di, real(1));
 #pragma unroll
-    for (int j = 0; j < 15; j++) shL[j] = L[j];
+    for (int j = 0; j < 15; j++) stsv(lds, eo + (oL + j), L[j], lead);
 #pragma unroll
-    for (int j = 0; j < 6; j++) shD[j] = Di[j];
+    for (int j = 0; j < 6; j++) stsv(lds, eo + (oD + j), Di[j], lead);
     if (pass == 0) {
       // ---- servo forces, qfrc_smooth, qacc_smooth = M^-1 qfrc_smooth (block solve in the leg layout)
       vr y[3], t[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
-        vr ctrl = ldsv(sh.ctrl, leg * 3 + k), qd = ldsv(sh.qvel, leg * 3 + (6 + k));
+        vr ctrl = LDL(ctrl, leg * 3 + k), qd = LDL(qvel, leg * 3 + (6 + k));
         ctrl = vmin(vmax(ctrl, vr(-M.ctrl_max)), vr(M.ctrl_max));
         y[k] = M.kv * ctrl - M.kv * qd - cl[k];
-        stsv(sh.qfs, leg * 3 + (6 + k), y[k], isleg);
+        STL(qfs, leg * 3 + (6 + k), y[k]);
       }
       ldl3_solve(t, Mi, y);
-      real xb[6];
+      vr xb[6];
 #pragma unroll
       for (int j = 0; j < 6; j++) {
         vr wy = W[0][j] * y[0] + W[1][j] * y[1] + W[2][j] * y[2];
         xb[j] = -cbias[j] - legsum<real>(wy, isleg);
-        sh.qfs[j] = -cbias[j];
+        STG(qfs, j, -cbias[j]);
       }
       ldl6_solve(L, Di, xb);
 #pragma unroll
-      for (int j = 0; j < 6; j++) sh.qas[j] = xb[j];
+      for (int j = 0; j < 6; j++) STG(qas, j, xb[j]);
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         vr x = t[k];
 #pragma unroll
         for (int j = 0; j < 6; j++) x = x - W[k][j] * xb[j];
-        stsv(sh.qas, leg * 3 + (6 + k), x, isleg);
+        STL(qas, leg * 3 + (6 + k), x);
       }
     }
   }
   wave_sync();
+#undef LDG
+#undef STG
+#undef LDL
+#undef STL
 }
-
 
 // =========================================================================================  convex-convex (MPR)
 // Tibia vs tibia (contype 2 / conaffinity 3, reference mjmodel.xml:47...). Restates libccd's ccdMPRPenetration the way
@@ -839,11 +876,55 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
 
 // =========================================================================================  stage B
 // Floor (z = 0) against the convex hulls of base_link and the six tibias.
+// Support vertex of hull g along ld (mesh frame) by exhaustive scan, lowest index wins ties (the reference rule).
+template <class real> NM_FN int support_exhaustive(const Model<real>& M, const real* ld, int nvert, int vadr) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  vr best = vr(real(-1e30));
+  V<int> ibest = lane;
+  for (int it = 0; it * NM_WAVE < nvert; it++) {
+    V<int> vi = lane + it * NM_WAVE;
+    VB ok = vi < nvert;
+    vr v[3];
+    gld3(M.hullv, (sel(ok, vi, V<int>(0)) + vadr) * 4, v);
+    vr val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
+    VB take = ok & (val > best);
+    best = sel(take, val, best);
+    ibest = sel(take, vi, ibest);
+  }
+  real sv; int si;
+  wargmax(best, ibest, &sv, &si);
+  return si;
+}
+
+// Floor (z = 0) against the convex hulls of base_link and the six tibias. Like mjc_support, the search for the
+// support vertex is warm-started: lanes 0..maxnbr-1 evaluate the hull neighbours of last time's support vertex and lane
+// 63 the vertex itself, for ALL seven meshes with independent (batched) gathers; only when a neighbour ties or beats it
+// does the mesh fall back to the exhaustive scan - so the result is always the exhaustive one (lowest index on ties).
+// The same neighbour data then yields the <= 3 extra plane-mesh contacts.
+constexpr int kSelfLane = 63;
 template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped, bool pairs = true) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
-  int ncon = 0;
   const real bz = sh.qpos[2];
+  const VB nbl = lane < M.maxnbr;
+  const V<int> nbslot = sel(nbl, lane, V<int>(0));
+  V<int> nb[kNCOL];
+  vr vv[kNCOL][3];
+  int cur[kNCOL];
+#pragma unroll
+  for (int g = 0; g < kNCOL; g++) {
+    const int vadr = (int)M.colc[kColN * g + 6];
+    cur[g] = uniform(sh.hcache[g]);
+    nb[g] = sel(lane == kSelfLane, V<int>(cur[g]), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + cur[g]) * M.maxnbr), V<int>(-1)));
+  }
+#pragma unroll
+  for (int g = 0; g < kNCOL; g++) {
+    const int vadr = (int)M.colc[kColN * g + 6];
+    gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
+  }
+  int ncon = 0;
+#pragma unroll
   for (int g = 0; g < kNCOL; g++) {
     const real* R = sh.colR + 9 * g;
     const real* p = sh.colp + 3 * g;
@@ -854,29 +935,27 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     if (cz - cc[3] > real(0)) continue;
     const int nvert = (int)cc[5], vadr = (int)cc[6];
     const real ld[3] = {-R[6], -R[7], -R[8]};  // -normal in the mesh frame
-    vr best = vr(real(-1e30));
-    V<int> ibest = lane;
-    for (int it = 0; it * NM_WAVE < nvert; it++) {
-      V<int> vi = lane + it * NM_WAVE;
-      VB ok = vi < nvert;
-      V<int> ad = (sel(ok, vi, V<int>(0)) + vadr) * 4;
-      vr val = ld[0] * gldv(M.hullv, ad) + ld[1] * gldv(M.hullv, ad + 1) + ld[2] * gldv(M.hullv, ad + 2);
-      VB take = ok & (val > best);
-      best = sel(take, val, best);
-      ibest = sel(take, vi, ibest);
+    V<int> nbg = nb[g];
+    vr v[3] = {vv[g][0], vv[g][1], vv[g][2]};
+    vr val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
+    int si = cur[g];
+    real sv = rdlane(val, kSelfLane);
+    if (wany(nbl & (nbg >= 0) & (val >= vr(sv)))) {  // not (strictly) the maximiser any more: full search, then its neighbours
+      si = support_exhaustive(M, ld, nvert, vadr);
+      sh.hcache[g] = si;
+      sh.nfallback += 1;
+      nbg = sel(lane == kSelfLane, V<int>(si), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + si) * M.maxnbr), V<int>(-1)));
+      gld3(M.hullv, (vmax(nbg, V<int>(0)) + vadr) * 4, v);
+      val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
+      sv = rdlane(val, kSelfLane);
     }
-    real sv; int si;
-    wargmax(best, ibest, &sv, &si);
     const real dist = pz - sv;
     if (dist >= real(0)) continue;
     if (ncon >= kMaxCon) { *dropped += 1; continue; }
-    const real* v0 = M.hullv + 4 * (vadr + si);
-    real first[3];
-    {
-      real t[3];
-      matvec3(t, R, v0);
-      first[0] = p[0] + t[0]; first[1] = p[1] + t[1]; first[2] = p[2] + t[2] - real(0.5) * dist;
-    }
+    vr pnt[3];
+    matvec3(pnt, R, v);
+    pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
+    const real first[3] = {rdlane(pnt[0], kSelfLane), rdlane(pnt[1], kSelfLane), rdlane(pnt[2], kSelfLane) - real(0.5) * dist};
     sh.cpos[3 * ncon] = first[0]; sh.cpos[3 * ncon + 1] = first[1]; sh.cpos[3 * ncon + 2] = first[2];
     sh.cdist[ncon] = dist;
     sh.cleg[ncon] = g - 1;
@@ -885,18 +964,9 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     ncon++;
     // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
     const real tol = M.tol_planemesh * cc[3];
-    VB valid = lane < M.maxnbr;
-    V<int> nb = gldv(M.hullnbr, sel(valid, lane, V<int>(0)) + (vadr + si) * M.maxnbr);
-    valid = valid & (nb >= 0);
-    V<int> ad = (sel(valid, nb, V<int>(0)) + vadr) * 4;
-    vr v[3] = {gldv(M.hullv, ad), gldv(M.hullv, ad + 1), gldv(M.hullv, ad + 2)};
-    vr val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
-    vr pnt[3];
-    matvec3(pnt, R, v);
-    pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
     vr dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
     vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
-    VB ok = valid & (val > vr(pz)) & !(vsqrt(d2) < vr(tol));
+    VB ok = nbl & (nbg >= 0) & (val > vr(pz)) & !(vsqrt(d2) < vr(tol));
     uint64_t m = ballot(ok);
     for (int extra = 0; extra < 3 && m; extra++) {
       int e = __builtin_ctzll(m);
@@ -922,7 +992,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
 
 // =========================================================================================  stage C
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
-template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
+template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const int ncon = uniform(sh.ncon), nefc = 4 * ncon;
@@ -1011,14 +1081,14 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   for (int k = 0; k < 3; k++) Jl[k] = sel(act, Jl[k], vr(real(0)));
   // publish the sparse row for the projection sweep
 #pragma unroll
-  for (int j = 0; j < 6; j++) stsv(sh.jrow, lane * kJRow + j, Jb[j], lane < kMaxRow);
+  for (int j = 0; j < 6; j++) stsv(jrow, lane * kJRow + j, Jb[j], lane < kMaxRow);
 #pragma unroll
-  for (int k = 0; k < 3; k++) stsv(sh.jrow, lane * kJRow + (6 + k), Jl[k], lane < kMaxRow);
-  stsv(sh.jrow, lane * kJRow + 9, to_real<real>(L), lane < kMaxRow);
+  for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (6 + k), Jl[k], lane < kMaxRow);
+  stsv(jrow, lane * kJRow + 9, to_real<real>(L), lane < kMaxRow);
   if (anypair) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) stsv(sh.jrow, lane * kJRow + (10 + k), Jm[k], lane < kMaxRow);
-    stsv(sh.jrow, lane * kJRow + 13, to_real<real>(L1), lane < kMaxRow);
+    for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (10 + k), Jm[k], lane < kMaxRow);
+    stsv(jrow, lane * kJRow + 13, to_real<real>(L1), lane < kMaxRow);
   }
 
   // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
@@ -1103,7 +1173,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   for (int i = 0; i < kMaxRow; i++) {
     A[i] = vr(real(0));
     if (i < nefc) {
-      const real* jr = sh.jrow + i * kJRow;
+      const real* jr = jrow + i * kJRow;
       vr a = jr[0] * B[0] + jr[1] * B[1] + jr[2] * B[2] + jr[3] * B[3] + jr[4] * B[4] + jr[5] * B[5];
       const int Li = uniform((int)jr[9]);
       switch (Li) {
@@ -1154,32 +1224,36 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
 #ifdef NM_DEBUG_SOLVER
   stsv(sh.dbg_b, lane, bb, lane < kMaxRow); stsv(sh.dbg_a, lane, ARjj, lane < kMaxRow); stsv(sh.dbg_f0, lane, f, lane < kMaxRow);
 #endif
-  // ---- mj_solPGS: Gauss-Seidel over rows; every lane keeps its residual current by a rank-1 update
+  // ---- mj_solPGS: Gauss-Seidel over rows; every lane keeps its residual current by a rank-1 update.
+  // Per row: all lanes evaluate their own candidate, lane i's delta is broadcast (v_readlane) and applied.
+  const vr hA = real(0.5) * ARjj;
   for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
-    real improvement = real(0);
+    vr impv = vr(real(0));  // per-lane improvement: lane i adds its own row's cost change
+    const V<int> lv = opaque_lane();
 #pragma unroll
     for (int i = 0; i < kMaxRow; i++) {
       if (i < nefc) {
         vr res = g + Rr * f;
         vr fn = vmax(f - res * ARinv, vr(real(0)));
         vr dl = fn - f;
-        vr change = real(0.5) * dl * dl * ARjj + dl * res;
-        VB bad = change > vr(real(1e-10));
+        vr change = dl * (hA * dl + res);          // 0.5 dl^2 AR_ii + dl res
+        VB bad = change > vr(real(1e-10));         // costChange: revert an update that does not decrease the cost
         dl = sel(bad, vr(real(0)), dl);
         change = sel(bad, vr(real(0)), change);
-        real di = rdlane(dl, i);
-        improvement = improvement - rdlane(change, i);
-        g += A[i] * di;
-        f = wrlane(f, rdlane(f + dl, i), i);
+        g += A[i] * rdlane(dl, i);
+        VB me = lv == i;
+        f = sel(me, f + dl, f);
+        impv = sel(me, impv - change, impv);
       }
     }
     sh.it_pgs = iter + 1;
-    if (improvement * M.pgs_scale < M.pgs_tol) break;
+    if (wsum<real>(impv) * M.pgs_scale < M.pgs_tol) break;
   }
   // ---- mj_solNoSlip: per opposing pyramid pair, exact 1-D minimisation along (f0 - f1) without R
   for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
     real improvement = real(0);
     if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
+    const V<int> lv = opaque_lane();
 #pragma unroll
     for (int p = 0; p < kMaxRow / 2; p++) {
       if (2 * p < nefc) {
@@ -1202,8 +1276,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
         if (change > real(1e-10)) { d0 = real(0); d1 = real(0); change = real(0); }
         improvement = improvement - change;
         g += A[j0] * d0 + A[j1] * d1;
-        f = wrlane(f, o0 + d0, j0);
-        f = wrlane(f, o1 + d1, j1);
+        f = sel(lv == j0, vr(o0 + d0), sel(lv == j1, vr(o1 + d1), f));
       }
     }
     sh.it_noslip = iter + 1;
@@ -1255,100 +1328,138 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   wave_sync();
 }
 
-template <class real> NM_COLD void stage_constraint_pairs(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
-  stage_constraint_body<real, true>(sh, M, last, nosweep);
+template <class real> NM_COLD void stage_constraint_pairs(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep) {
+  stage_constraint_body<real, true>(sh, jrow, M, last, nosweep);
 }
-template <class real> NM_FN void stage_constraint(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep = false) {
-  if (uniform(sh.anypair) != 0) stage_constraint_pairs<real>(sh, M, last, nosweep);
-  else stage_constraint_body<real, false>(sh, M, last, nosweep);
+template <class real> NM_FN void stage_constraint(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep = false) {
+  if (uniform(sh.anypair) != 0) stage_constraint_pairs<real>(sh, jrow, M, last, nosweep);
+  else stage_constraint_body<real, false>(sh, jrow, M, last, nosweep);
 }
 
 // =========================================================================================  stage D
-// qacc (for the warm start), implicitfast velocity update, position integration. Returns "qacc is bad".
-template <class real> NM_FN bool stage_integrate(Sh<real>& sh, const Model<real>& M) {
+// qacc (for the warm start), implicitfast velocity update, position integration - all G envs of the wave at once
+// (lane groups as in stage A). An env whose qacc is bad (mj_checkAcc) is reset and advanced by the closed form of
+// "mj_resetData; mj_forward; integrate": free fall from qpos0 with zero ctrl.
+template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const Model<real>& M) {
   typedef V<real> vr;
-  const V<int> lane = lane_id();
-  const V<int> leg = lane % 6;
-  const VB isleg = lane < 6;
-  vr qacc_l[3], qint_l[3];
-  real qacc_b[6], qint_b[6];
+  real* lds = reinterpret_cast<real*>(&w.e[0]);
+  const Grp<real, G> gp;
+  const V<int> leg = gp.leg, eo = gp.eo;
+  const VB isleg = gp.isleg, lead = gp.lead;
+#define LDG(field, i) ldsv(lds, eo + (NM_OFS(field) + (i)))
+#define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
+  vr qacc_l[3], qint_l[3], qacc_b[6], qint_b[6];
 #pragma unroll
   for (int pass = 0; pass < 2; pass++) {
     // pass 0: qacc = qacc_smooth + M^-1 qfrc_constraint ; pass 1: (M + h kv I) qacc_int = qfrc_smooth + qfrc_constraint
-    const real* shMinv = pass ? sh.MinvH : sh.Minv;
-    const real* shW = pass ? sh.WH : sh.W;
-    const real* shL = pass ? sh.LbH : sh.Lb;
-    const real* shD = pass ? sh.DbiH : sh.Dbi;
+    const int oMinv = pass ? NM_OFS(MinvH) : NM_OFS(Minv), oW = pass ? NM_OFS(WH) : NM_OFS(W);
+    const int oL = pass ? NM_OFS(LbH) : NM_OFS(Lb), oD = pass ? NM_OFS(DbiH) : NM_OFS(Dbi);
     vr y[3], t[3], Mi[6];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      y[k] = ldsv(sh.qfc, leg * 3 + (6 + k));
-      if (pass) y[k] = y[k] + ldsv(sh.qfs, leg * 3 + (6 + k));
+      y[k] = LDL(qfc, leg * 3 + (6 + k));
+      if (pass) y[k] = y[k] + LDL(qfs, leg * 3 + (6 + k));
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) Mi[j] = ldsv(shMinv, leg * 6 + j);
+    for (int j = 0; j < 6; j++) Mi[j] = ldsv(lds, eo + leg * 6 + (oMinv + j));
     ldl3_solve(t, Mi, y);
-    real xb[6];
+    vr xb[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      vr wy = ldsv(shW, leg * 18 + j) * y[0] + ldsv(shW, leg * 18 + (6 + j)) * y[1] + ldsv(shW, leg * 18 + (12 + j)) * y[2];
-      xb[j] = sh.qfc[j] + (pass ? sh.qfs[j] : real(0)) - legsum<real>(wy, isleg);
+      vr wy = ldsv(lds, eo + leg * 18 + (oW + j)) * y[0] + ldsv(lds, eo + leg * 18 + (oW + 6 + j)) * y[1] +
+              ldsv(lds, eo + leg * 18 + (oW + 12 + j)) * y[2];
+      xb[j] = LDG(qfc, j) - legsum<real>(wy, isleg);
+      if (pass) xb[j] = xb[j] + LDG(qfs, j);
     }
-    ldl6_solve(shL, shD, xb);
+    {
+      vr L[15], Di[6];
+#pragma unroll
+      for (int j = 0; j < 15; j++) L[j] = ldsv(lds, eo + (oL + j));
+#pragma unroll
+      for (int j = 0; j < 6; j++) Di[j] = ldsv(lds, eo + (oD + j));
+      ldl6_solve(L, Di, xb);
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       vr x = t[k];
 #pragma unroll
-      for (int j = 0; j < 6; j++) x = x - ldsv(shW, leg * 18 + (6 * k + j)) * xb[j];
-      if (pass) qint_l[k] = x; else qacc_l[k] = x + ldsv(sh.qas, leg * 3 + (6 + k));
+      for (int j = 0; j < 6; j++) x = x - ldsv(lds, eo + leg * 18 + (oW + 6 * k + j)) * xb[j];
+      if (pass) qint_l[k] = x; else qacc_l[k] = x + LDL(qas, leg * 3 + (6 + k));
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) { if (pass) qint_b[j] = xb[j]; else qacc_b[j] = xb[j] + sh.qas[j]; }
+    for (int j = 0; j < 6; j++) { if (pass) qint_b[j] = xb[j]; else qacc_b[j] = xb[j] + LDG(qas, j); }
   }
-  // mj_checkAcc
-  VB badv = visbad(qacc_l[0]) | visbad(qacc_l[1]) | visbad(qacc_l[2]);
-  bool bad = wany(badv & isleg);
+  // mj_checkAcc, per env
+  VB badl = (visbad(qacc_l[0]) | visbad(qacc_l[1]) | visbad(qacc_l[2])) & isleg;
 #pragma unroll
-  for (int j = 0; j < 6; j++) bad = bad | visbad(qacc_b[j]);
-  if (bad) return true;
+  for (int j = 0; j < 6; j++) badl = badl | visbad(qacc_b[j]);
+  const VB gbad = gsum8(sel(badl & gp.gact, V<int>(1), V<int>(0))) > 0;
+  const VB okl = isleg & !gbad, okb = lead & !gbad;
   wave_sync();
   // mj_advance: qacc_warmstart <- qacc ; qvel += h qacc_int ; qpos integrates the NEW velocity
-  real nv[6];
+  vr nv[6];
 #pragma unroll
-  for (int j = 0; j < 6; j++) {
-    nv[j] = sh.qvel[j] + M.h * qint_b[j];
-    sh.warm[j] = qacc_b[j];
-  }
+  for (int j = 0; j < 6; j++) nv[j] = LDG(qvel, j) + M.h * qint_b[j];
+  vr np_[3], nq[4];
 #pragma unroll
-  for (int j = 0; j < 6; j++) sh.qvel[j] = nv[j];
-#pragma unroll
-  for (int j = 0; j < 3; j++) sh.qpos[j] = sh.qpos[j] + M.h * nv[j];
+  for (int j = 0; j < 3; j++) np_[j] = LDG(qpos, j) + M.h * nv[j];
   {  // mju_quatIntegrate: q <- q * exp(h w), w in the body frame
-    real ax[3] = {nv[3], nv[4], nv[5]};
-    real n = vsqrt(ax[0] * ax[0] + ax[1] * ax[1] + ax[2] * ax[2]);
-    real qr[4] = {real(1), real(0), real(0), real(0)};
-    if (n >= real(1e-15)) {
-      real ang = M.h * n, s, c;
-      vsincos(real(0.5) * ang, &s, &c);
-      if (ang != real(0)) { qr[0] = c; qr[1] = ax[0] / n * s; qr[2] = ax[1] / n * s; qr[3] = ax[2] / n * s; }
-    }
-    real a[4] = {sh.qpos[3], sh.qpos[4], sh.qpos[5], sh.qpos[6]};
-    real t[4] = {a[0] * qr[0] - a[1] * qr[1] - a[2] * qr[2] - a[3] * qr[3], a[0] * qr[1] + a[1] * qr[0] + a[2] * qr[3] - a[3] * qr[2],
-                 a[0] * qr[2] - a[1] * qr[3] + a[2] * qr[0] + a[3] * qr[1], a[0] * qr[3] + a[1] * qr[2] - a[2] * qr[1] + a[3] * qr[0]};
-    real nn = vsqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);  // mj_kinematics normalises before use
-    sh.qpos[3] = t[0] / nn; sh.qpos[4] = t[1] / nn; sh.qpos[5] = t[2] / nn; sh.qpos[6] = t[3] / nn;
+    vr n = vsqrt(nv[3] * nv[3] + nv[4] * nv[4] + nv[5] * nv[5]);
+    VB rot = !(n < vr(real(1e-15)));
+    vr ns = sel(rot, n, vr(real(1)));
+    vr ang = M.h * n, sn, cs;
+    vsincos(real(0.5) * ang, &sn, &cs);
+    rot = rot & (ang != vr(real(0)));
+    vr qr[4] = {sel(rot, cs, vr(real(1))), sel(rot, nv[3] / ns * sn, vr(real(0))), sel(rot, nv[4] / ns * sn, vr(real(0))),
+                sel(rot, nv[5] / ns * sn, vr(real(0)))};
+    vr a[4] = {LDG(qpos, 3), LDG(qpos, 4), LDG(qpos, 5), LDG(qpos, 6)};
+    vr t[4] = {a[0] * qr[0] - a[1] * qr[1] - a[2] * qr[2] - a[3] * qr[3], a[0] * qr[1] + a[1] * qr[0] + a[2] * qr[3] - a[3] * qr[2],
+               a[0] * qr[2] - a[1] * qr[3] + a[2] * qr[0] + a[3] * qr[1], a[0] * qr[3] + a[1] * qr[2] - a[2] * qr[1] + a[3] * qr[0]};
+    vr nn = vsqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);  // mj_kinematics normalises before use
+#pragma unroll
+    for (int j = 0; j < 4; j++) nq[j] = t[j] / nn;
   }
+  vr jq[3], jv[3];
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    V<int> di = leg * 3 + (6 + k);
-    vr qd = ldsv(sh.qvel, di) + M.h * qint_l[k];
-    vr q = ldsv(sh.qpos, di + 1) + M.h * qd;
-    stsv(sh.qvel, di, qd, isleg);
-    stsv(sh.qpos, di + 1, q, isleg);
-    stsv(sh.warm, di, qacc_l[k], isleg);
+    jv[k] = LDL(qvel, leg * 3 + (6 + k)) + M.h * qint_l[k];
+    jq[k] = LDL(qpos, leg * 3 + (7 + k)) + M.h * jv[k];
   }
   wave_sync();
-  return false;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    stsv(lds, eo + (NM_OFS(qvel) + j), nv[j], okb);
+    stsv(lds, eo + (NM_OFS(warm) + j), qacc_b[j], okb);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) stsv(lds, eo + (NM_OFS(qpos) + j), np_[j], okb);
+#pragma unroll
+  for (int j = 0; j < 4; j++) stsv(lds, eo + (NM_OFS(qpos) + 3 + j), nq[j], okb);
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    stsv(lds, eo + leg * 3 + (NM_OFS(qvel) + 6 + k), jv[k], okl);
+    stsv(lds, eo + leg * 3 + (NM_OFS(qpos) + 7 + k), jq[k], okl);
+    stsv(lds, eo + leg * 3 + (NM_OFS(warm) + 6 + k), qacc_l[k], okl);
+  }
+  wave_sync();
+  // bad envs (rare): mj_resetData, then one free-fall step from qpos0 (no contacts at z0, ctrl = 0 -> qacc = (0,0,-g,0...))
+  for (int e = 0; e < G; e++) {
+    if (rdlane(sel(gbad, V<int>(1), V<int>(0)), 8 * e) != 0) {
+      Sh<real>& sh = w.e[e];
+      const V<int> lane = lane_id();
+      sh.nwarn += 1;
+      vr q0 = gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0)));
+      real vz = -M.grav * M.h;
+      q0 = sel(lane == 2, q0 + vz * M.h, q0);
+      stsv(sh.qpos, lane, q0, lane < kNQ);
+      stsv(sh.qvel, lane, sel(lane == 2, vr(vz), vr(real(0))), lane < kNV);
+      stsv(sh.warm, lane, sel(lane == 2, vr(-M.grav), vr(real(0))), lane < kNV);
+      stsv(sh.ctrl, lane, real(0), lane < kNU);
+      wave_sync();
+    }
+  }
+#undef LDG
+#undef LDL
 }
 
 template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) {  // mj_resetData
@@ -1360,35 +1471,39 @@ template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) 
   wave_sync();
 }
 
-// mj_step(model, data, 1)
-template <class real> NM_FN void substep(Sh<real>& sh, const Model<real>& M, bool last, int* dropped, int ablate) {
+// mj_step(model, data, 1) for the G envs of the wave
+template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<real>& M, bool last, int* dropped, int ablate) {
   const V<int> lane = lane_id();
-  {  // mj_checkPos / mj_checkVel
-    VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
-             (visbad(ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0)))) & (lane < kNV));
-    if (wany(bad)) { sh.nwarn += 1; reset_data(sh, M); }
+  for (int e = 0; e < G; e++) {
+    Sh<real>& sh = w.e[e];
+    {  // mj_checkPos / mj_checkVel
+      VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
+               (visbad(ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0)))) & (lane < kNV));
+      if (wany(bad)) { sh.nwarn += 1; reset_data(sh, M); }
+    }
+    {  // mj_kinematics normalises the free joint's quaternion in qpos
+      real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
+      real a = sh.qpos[3] / n, b = sh.qpos[4] / n, c = sh.qpos[5] / n, d = sh.qpos[6] / n;
+      wave_sync();
+      sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
+    }
   }
-  {  // mj_kinematics normalises the free joint's quaternion in qpos
-    real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
-    real a = sh.qpos[3] / n, b = sh.qpos[4] / n, c = sh.qpos[5] / n, d = sh.qpos[6] / n;
-    wave_sync();
-    sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
-    wave_sync();
-  }
-  for (int attempt = 0; attempt < 2; attempt++) {
-    if (!(ablate & 8)) stage_smooth(sh, M, last);
+  wave_sync();
+  if (!(ablate & 8)) stage_smooth(w, M, last);
+  for (int e = 0; e < G; e++) {
+    Sh<real>& sh = w.e[e];
     if (!(ablate & 1)) stage_collide(sh, M, dropped, !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     if (ablate & 4) { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
-    stage_constraint(sh, M, last, (ablate & 2) != 0);
-    bool bad = stage_integrate(sh, M);
-    if (!bad) break;
-    sh.nwarn += 1;  // mj_checkAcc: reset, run the forward pass again, integrate
-    reset_data(sh, M);
+    stage_constraint(sh, w.jrow, M, last, (ablate & 2) != 0);
   }
+  stage_integrate(w, M);
 }
 
 // =========================================================================================  env step
-template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env) {
+template <class real> struct EnvRegs { V<real> act, prev_act, prev_dofvel, defp; };  // per-env values carried across the physics
+
+// load one env's state into its LDS image, action -> servo command (E1)
+template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env, EnvRegs<real>& rg) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const VB l18 = lane < kNU;
@@ -1398,11 +1513,13 @@ template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, co
   stsv(sh.qvel, lane, gldv(A.qvel, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
   stsv(sh.warm, lane, gldv(A.qwarm, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
   sh.nwarn = 0;
+  sh.nfallback = 0;
+  stsv(sh.hcache, lane, gldv(A.hullcache, sel(lane < 8, lane, V<int>(0)) + env * 8), lane < 8);
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
   V<float> a_in = gldv(A.actions, l18c + env * kNU);
   V<float> af = a_in * M.action_scale;
   af = vmin(vmax(af, V<float>(-M.clip_actions)), V<float>(M.clip_actions));
-  vr act, prev_act, prev_dofvel, dofpos_old;
+  vr act, prev_act = vr(real(0)), prev_dofvel = vr(real(0)), dofpos_old;
   vr defp;
   {
     V<int> m3 = lane % 3;
@@ -1421,11 +1538,21 @@ template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, co
   } else {  // dynamics-only mode (BASELINE config 2): same PD law on the current joint angles, no env buffers
     stsv(sh.ctrl, lane, ((act - defp) - ldsv(sh.qpos, l18c + 7)) * M.p_gain, l18);
   }
+  rg.act = act; rg.prev_act = prev_act; rg.prev_dofvel = prev_dofvel; rg.defp = defp;
   wave_sync();
-  // ---- E2 (env.py:200): mj_step(model, data, decimation)
-  int dropped = 0;
-  for (int s = 0; s < A.nsub; s++) substep(sh, M, s == A.nsub - 1, &dropped, A.ablate);
+}
+
+// store one env's state, run the env epilogue (E3-E8). `live` = the slot holds a real env (last wave may be padded)
+template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env, const EnvRegs<real>& rg,
+                                            int dropped, bool live) {
+  typedef V<real> vr;
+  if (!live) return;
+  const V<int> lane = lane_id();
+  const VB l18 = lane < kNU;
+  const V<int> l18c = sel(l18, lane, V<int>(0));
+  const vr act = rg.act, prev_act = rg.prev_act, prev_dofvel = rg.prev_dofvel, defp = rg.defp;
   // ---- store physics state
+  gstv(A.hullcache, lane + env * 8, ldsv(sh.hcache, sel(lane < 8, lane, V<int>(0))), lane < 8);
   gstv(A.qpos, lane + env * kNQ, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
   gstv(A.qvel, lane + env * kNV, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
   gstv(A.qwarm, lane + env * kNV, ldsv(sh.warm, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
@@ -1456,6 +1583,11 @@ template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, co
     A.stat_cnt[1] += dropped; A.stat_cnt[2] += sh.nwarn;
 #else
     if (threadIdx.x == 0) { atomicAdd(A.stat_cnt + 1, dropped); atomicAdd(A.stat_cnt + 2, sh.nwarn); }
+#endif
+  }
+  if (A.stat_cnt && sh.nfallback) {
+#ifndef NM_EMUL
+    if (threadIdx.x == 0) atomicAdd(A.stat_cnt + 3, sh.nfallback);
 #endif
   }
   if (A.physics_only) return;
@@ -1594,6 +1726,23 @@ template <class real> NM_FN void env_step(Sh<real>& sh, const Model<real>& M, co
     A.rew[env] = (float)rew;
     A.done[env] = reset ? 1 : 0;
     A.timeout_now[env] = time_out ? 1.0f : 0.0f;
+  }
+}
+
+// one wavefront = G consecutive envs (E2, env.py:200: mj_step(model, data, decimation) between load and epilogue)
+template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave) {
+  EnvRegs<real> rg[G];
+#pragma unroll
+  for (int e = 0; e < G; e++) {
+    int env = wave * G + e;
+    env_load(w.e[e], M, A, env < A.N ? env : A.N - 1, rg[e]);
+  }
+  int dropped = 0;
+  for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, A.ablate);
+#pragma unroll
+  for (int e = 0; e < G; e++) {
+    int env = wave * G + e;
+    env_finish(w.e[e], M, A, env, rg[e], e == 0 ? dropped : 0, env < A.N);
   }
 }
 

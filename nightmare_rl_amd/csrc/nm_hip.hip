@@ -22,12 +22,15 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 #ifndef NM_WAVES_PER_SIMD
 #define NM_WAVES_PER_SIMD 2  /* measured: 198 us at 2 (no spills) vs 217 us at 4 (616 B/lane scratch), 4096 envs */
 #endif
-template <class real>
+#ifndef NM_ENVS_PER_WAVE
+#define NM_ENVS_PER_WAVE 2
+#endif
+template <class real, int G>
 __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
-  __shared__ nm::Sh<real> sh;
-  const int env = blockIdx.x;
-  if (env >= A.N) return;
-  nm::env_step(sh, *Mp, A, env);
+  __shared__ nm::ShW<real, G> sh;
+  const int wave = blockIdx.x;
+  if (wave * G >= A.N) return;
+  nm::wave_step<real, G>(sh, *Mp, A, wave);
 }
 
 // reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
@@ -77,8 +80,10 @@ __global__ void k_finalize(int N, real* stat_sum, int* stat_cnt, float* ep_stats
     stat_cnt[0] = 0;
     counters[0] += stat_cnt[1];
     counters[1] += stat_cnt[2];
+    counters[2] += stat_cnt[3];
     stat_cnt[1] = 0;
     stat_cnt[2] = 0;
+    stat_cnt[3] = 0;
   }
 }
 
@@ -142,8 +147,8 @@ template <class real> struct Env : nm_env {
     size_t n_ = (size_t)N;
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
         dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * 8) ||
-        dalloc(&A.rngctr, n_) || dalloc(&A.stat_sum, 8) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
-        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 2))
+        dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, 8) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4))
       return 1;
     if (dalloc(&M_dev, 1)) return 1;
     HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));
@@ -200,7 +205,8 @@ template <class real> struct Env : nm_env {
       prof_used++;
       HIPCHK(hipEventRecord(e0, s));
     }
-    hipLaunchKernelGGL(k_env_step<real>, dim3(N), dim3(64), 0, s, (const nm::Model<real>*)M_dev, a);
+    constexpr int G = sizeof(real) == 8 ? 1 : NM_ENVS_PER_WAVE;  // the fp64 verification build keeps one env per wave (LDS)
+    hipLaunchKernelGGL((k_env_step<real, G>), dim3((N + G - 1) / G), dim3(64), 0, s, (const nm::Model<real>*)M_dev, a);
     HIPCHK(hipGetLastError());
     if (prof_on) HIPCHK(hipEventRecord(e1, s));
     if (physics_only) return 0;
@@ -251,9 +257,9 @@ template <class real> struct Env : nm_env {
   int counters(int64_t* out) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipDeviceSynchronize());
-    long long c[2];
+    long long c[3];
     HIPCHK(hipMemcpy(c, counters_dev, sizeof c, hipMemcpyDeviceToHost));
-    out[0] = c[0]; out[1] = c[1];
+    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
     return 0;
   }
   void set_dbg(void* p) override { A.dbg = (real*)p; }

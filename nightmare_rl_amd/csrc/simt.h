@@ -63,6 +63,9 @@ template <class T> NM_FN T wrlane(T x, T v, int l) {
   asm volatile("" : "+v"(ln));
   return ln == l ? v : x;
 }
+// lane id that the optimiser cannot see through: compares against it stay inside the loop they are written in (hoisting
+// 64 loop-invariant `lane == i` masks out of the solver sweeps costs 128 SGPRs and spills the scalar file)
+NM_FN int opaque_lane() { int ln = (int)threadIdx.x; asm volatile("" : "+v"(ln)); return ln; }
 template <class T> NM_FN T uniform(T x) { return rdlane(x, 0); }
 NM_FN bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
 // ---- DPP lane permutations inside a row of 16 lanes (no LDS traffic, ~VALU latency)
@@ -82,6 +85,13 @@ template <class T> NM_FN T wsum8(T x) {
   x = x + dpp<NM_DPP_QUAD_XOR2>(x);
   x = x + dpp<NM_DPP_HALF_MIRROR>(x);
   return rdlane(x, 0);
+}
+// sum inside every aligned group of 8 lanes; each lane of the group gets the group total (no broadcast needed)
+template <class T> NM_FN T gsum8(T x) {
+  x = x + dpp<NM_DPP_QUAD_XOR1>(x);
+  x = x + dpp<NM_DPP_QUAD_XOR2>(x);
+  x = x + dpp<NM_DPP_HALF_MIRROR>(x);
+  return x;
 }
 // sum of all 64 lanes (wave-uniform); fixed association order: 2,4,8,16 inside rows, then (r0+r1)+(r2+r3)
 template <class T> NM_FN T wsum(T x) {
@@ -122,6 +132,9 @@ template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; }
 template <class T> NM_FN T gldv(const T* p, int i) { return p[i]; }
 template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) p[i] = v; }
+// 3 consecutive values from a 4-element-aligned record: one vector load per lane
+NM_FN void gld3(const float* p, int i, float* o) { const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
+NM_FN void gld3(const double* p, int i, double* o) { const double4 t = *reinterpret_cast<const double4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 NM_FN void wave_sync() { __syncthreads(); }
 // keep the scheduler from hoisting a later phase's loads across this point (they would sit in VGPRs and spill)
 NM_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
@@ -187,6 +200,7 @@ template <class T> NM_FN T to_real(int a) { return (T)a; }
 template <class T> NM_FN T rdlane(const V<T>& x, int l) { return x.v[l]; }
 template <class T> NM_FN T rdlane(T x, int) { return x; }
 template <class T> NM_FN V<T> wrlane(V<T> x, T v, int l) { x.v[l] = v; return x; }
+NM_FN V<int> opaque_lane() { return lane_id(); }
 template <class T> NM_FN T uniform(const V<T>& x) { return x.v[0]; }
 template <class T> NM_FN T uniform(T x) { return x; }
 template <class T> NM_FN V<T> shfl_xor(const V<T>& x, int m) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[i ^ m]; return r; }
@@ -194,6 +208,10 @@ template <class T> NM_FN V<T> shfl_xor1(const V<T>& x) { return shfl_xor(x, 1); 
 template <class T> NM_FN V<T> shfl_xor2(const V<T>& x) { return shfl_xor(x, 2); }
 template <class T> NM_FN V<T> half_mirror(const V<T>& x) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[(i & ~7) | (7 - (i & 7))]; return r; }
 template <class T> NM_FN V<T> row_mirror(const V<T>& x) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[(i & ~15) | (15 - (i & 15))]; return r; }
+template <class T> NM_FN V<T> gsum8(V<T> x) {
+  x = x + shfl_xor(x, 1); x = x + shfl_xor(x, 2); x = x + half_mirror(x);
+  return x;
+}
 template <class T> NM_FN T wsum8(V<T> x) {
   x = x + shfl_xor(x, 1); x = x + shfl_xor(x, 2); x = x + half_mirror(x);
   return x.v[0];
@@ -217,6 +235,8 @@ template <class T> NM_FN void stsv(T* a, const V<int>& i, T v, const VB& m) { fo
 template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p, i); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, const V<T>& v, const VB& m) { stsv(p, i, v, m); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, T v, const VB& m) { stsv(p, i, v, m); }
+template <class T> NM_FN void gld3(const T* p, const V<int>& i, V<T>* o) { for (int k = 0; k < NM_WAVE; k++) for (int c = 0; c < 3; c++) o[c].v[k] = p[i.v[k] + c]; }
+template <class T> NM_FN void gld3(const T* p, int i, T* o) { o[0] = p[i]; o[1] = p[i + 1]; o[2] = p[i + 2]; }
 NM_FN void wave_sync() {}
 NM_FN void sched_fence() {}
 }  // namespace simt

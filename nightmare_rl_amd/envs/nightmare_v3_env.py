@@ -192,9 +192,9 @@ class NightmareV3Env:
         _lib.check(self._L.nm_set_command_uniforms(self._h, None if a is None else a.ctypes.data))
 
     def counters(self):
-        out = np.zeros(2, np.int64)
+        out = np.zeros(3, np.int64)
         _lib.check(self._L.nm_get_counters(self._h, out.ctypes.data))
-        return dict(contacts_dropped=int(out[0]), bad_state_resets=int(out[1]))
+        return dict(contacts_dropped=int(out[0]), bad_state_resets=int(out[1]), hull_search_fallbacks=int(out[2]))
 
     def set_debug_buffer(self, t):
         self._dbg = t

@@ -8,12 +8,16 @@ cfg = NightmareV3Config(); cfg.env.num_envs = N
 acts = (torch.rand(16, N, 18, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda()
 env = NightmareV3Env(cfg, seed=0); env.reset()
 mask = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+for i in range(300): env.step(acts[i % 16])          # settle with the real kernel
+q0 = env.get_state()
 env._L.nm_set_ablation(env._h, mask)
-for i in range(300): env.step(acts[i % 16])
 res = []
 for rep in range(3):
+    if mask: env.set_state(*q0)                       # ablated physics drifts: restart every rep from the settled state
     env.profile(True)
-    for i in range(200): env.step(acts[i % 16])
+    for i in range(40 if mask else 200): env.step(acts[i % 16])
     ms, n = env.profile(False)
     res.append(ms / n * 1e3)
 print(f"mask={mask} N={N} step kernel avg us: " + " ".join(f"{r:.1f}" for r in res) + f"  -> {N / min(res):.2f} M env-steps/s (kernel only)")
+
+print(env.counters(), "per geom-test fallback rate", env.counters()["hull_search_fallbacks"] / (env.common_step_counter * N * 2 * 7))

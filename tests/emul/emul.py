@@ -27,7 +27,7 @@ def lib():
         build()
         L = C.CDLL(LIB)
         L.emu_create.restype = C.c_void_p
-        L.emu_create.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64]
+        L.emu_create.argtypes = [C.c_int, C.c_int, C.c_uint64, C.c_int64, C.c_int]
         L.emu_destroy.argtypes = [C.c_void_p]
         L.emu_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int] + [C.c_void_p] * 3
         L.emu_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
@@ -46,10 +46,10 @@ WHAT = dict(qpos=(0, 25), qvel=(1, 24), qwarm=(2, 24), dofpos=(3, 18), dofvel=(4
 
 
 class EmulEnv:
-    def __init__(self, N, double=False, seed=0, env_off=0):
+    def __init__(self, N, double=False, seed=0, env_off=0, envs_per_wave=2):
         self.L = lib()
         self.N = N
-        self.h = self.L.emu_create(N, int(double), seed, env_off)
+        self.h = self.L.emu_create(N, int(double), seed, env_off, envs_per_wave)
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -26,9 +26,11 @@ template <class real> struct Emu : EmuBase {
   std::vector<real> qpos, qvel, qwarm, dofpos, dofvel, act, cmd, epsum;
   std::vector<int64_t> ep;
   std::vector<uint32_t> ctr;
+  std::vector<int> hcache;
   uint64_t seed;
   int64_t off;
-  Emu(int n, uint64_t s, int64_t o) : N(n), seed(s), off(o) {
+  int G = 1;
+  Emu(int n, uint64_t s, int64_t o, int g) : N(n), seed(s), off(o), G(g) {
     T.build();
     nmhost::EnvConfig cfg;
     T.fill_scalars(M, cfg);
@@ -36,7 +38,7 @@ template <class real> struct Emu : EmuBase {
     M.hullnbr = T.hullnbr.data(); M.footc = T.footc.data(); M.qpos0 = T.qpos0.data();
     qpos.assign((size_t)N * 25, 0); qvel.assign((size_t)N * 24, 0); qwarm.assign((size_t)N * 24, 0);
     dofpos.assign((size_t)N * 18, 0); dofvel.assign((size_t)N * 18, 0); act.assign((size_t)N * 18, 0);
-    cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * 8, 0); ep.assign(N, 0); ctr.assign(N, 0);
+    cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * 8, 0); ep.assign(N, 0); ctr.assign(N, 0); hcache.assign((size_t)N * 8, 0);
     for (int i = 0; i < N; i++)
       for (int j = 0; j < 25; j++) qpos[(size_t)i * 25 + j] = T.qpos0[j];
   }
@@ -58,12 +60,17 @@ template <class real> struct Emu : EmuBase {
     nm::Args<real> A{};
     A.N = N; A.seed = seed; A.env_offset = off;
     A.qpos = qpos.data(); A.qvel = qvel.data(); A.qwarm = qwarm.data(); A.dofpos = dofpos.data(); A.dofvel = dofvel.data();
-    A.act = act.data(); A.cmd = cmd.data(); A.epsum = epsum.data(); A.eplen = ep.data(); A.rngctr = ctr.data();
+    A.act = act.data(); A.cmd = cmd.data(); A.epsum = epsum.data(); A.eplen = ep.data(); A.rngctr = ctr.data(); A.hullcache = hcache.data();
     A.actions = actions; A.cmd_u = cmd_u ? cu.data() : nullptr;
     A.obs = obs; A.rew = rew; A.timeout_now = to; A.done = done; A.stat_sum = ssum.data(); A.stat_cnt = scnt;
     A.dbg = dbg ? dbgr.data() : nullptr; A.nsub = nsub; A.physics_only = physics_only;
-    static thread_local nm::Sh<real> sh;
-    for (int e = 0; e < N; e++) nm::env_step(sh, M, A, e);
+    if (G == 1) {
+      static thread_local nm::ShW<real, 1> sh;
+      for (int wv = 0; wv < N; wv++) nm::wave_step<real, 1>(sh, M, A, wv);
+    } else {
+      static thread_local nm::ShW<real, 2> sh;
+      for (int wv = 0; wv * 2 < N; wv++) nm::wave_step<real, 2>(sh, M, A, wv);
+    }
     if (dbg) for (size_t i = 0; i < dbgr.size(); i++) dbg[i] = (double)dbgr[i];
     if (stat_sum) for (int k = 0; k < 8; k++) stat_sum[k] = (double)ssum[k];
     if (stat_cnt) { stat_cnt[0] = scnt[0]; stat_cnt[1] = scnt[1]; }
@@ -72,9 +79,9 @@ template <class real> struct Emu : EmuBase {
 }  // namespace
 
 extern "C" {
-void* emu_create(int N, int use_double, uint64_t seed, int64_t env_off) {
-  if (use_double) return new Emu<double>(N, seed, env_off);
-  return new Emu<float>(N, seed, env_off);
+void* emu_create(int N, int use_double, uint64_t seed, int64_t env_off, int envs_per_wave) {
+  if (use_double) return new Emu<double>(N, seed, env_off, envs_per_wave);
+  return new Emu<float>(N, seed, env_off, envs_per_wave);
 }
 void emu_destroy(void* h) { delete (EmuBase*)h; }
 void emu_step(void* h, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done, float* to, int nsub, int physics_only,

@@ -90,3 +90,18 @@ def test_counter_rng_matches_oracle(emul, oracle_mod):
     o.step(a)
     np.testing.assert_allclose(e.get("cmd"), o.get_buffers()["commands"], atol=1e-15)
     assert np.abs(e.get("cmd")).sum() > 0
+
+
+def test_envs_per_wave_does_not_change_results(emul):
+    """Two envs per wavefront (lane groups in the leg stages) vs one env per wave: bitwise identical, odd N padded."""
+    N, T = 7, 30
+    rng = np.random.default_rng(8)
+    e1 = emul.EmulEnv(N, double=False, seed=3, envs_per_wave=1)
+    e2 = emul.EmulEnv(N, double=False, seed=3, envs_per_wave=2)
+    for t in range(T):
+        a = rng.uniform(-1, 1, (N, 18)).astype(np.float32)
+        o1 = e1.step(a)
+        o2 = e2.step(a)
+        for x, y in zip(o1, o2):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(e1.get("qpos"), e2.get("qpos"))
