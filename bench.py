@@ -142,6 +142,12 @@ def main():
         k_ms, k_n = env.profile(False)
         k_avg = k_ms / max(k_n, 1) * 1e-3
         achieved = B_FULL * E / k_avg / 1e9
+        traffic = None   # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this kernel (profiles/)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
+            traffic = tj["bytes_per_launch"] * (E / 4096.0)
+        except Exception:
+            pass
         # physics-only (BASELINE config 2) and step + 2x256 MLP policy forward (config 3), for DESIGN.md / the log
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -168,7 +174,7 @@ def main():
                                    "(18-DoF dynamics + floor contact, PGS x3 + noslip x4) + obs/reward/termination/reset",
                        "envs_per_gpu": E, "decimation": 2, "sharding": f"dp{world} by env id, all-gather of returns every {horizon} steps"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None, "kernel": "k_env_step<float>", "kernel_avg_us": k_avg * 1e6,
+                         "traffic": traffic, "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6,
                          "algorithmic_bytes_per_env_step": B_FULL,
                          "note": "latency/VALU-issue bound, not HBM bound: see DESIGN.md"},
             "physics_only_env_steps_per_s": phys,
