@@ -1,6 +1,10 @@
 // nm_policy.hip - ActorCritic actor forward (rsl_rl v1.0.2 ActorCritic.act mean path; reference call sites
 // play.py:122, train.py:40) as a batched GEMM chain on the matrix cores: exact-f32 MFMA (v_mfma_f32_32x32x2_f32),
-// bias + ELU fused into the accumulator epilogue. One wave computes a 32(envs) x 32(outputs) tile.
+// bias + ELU fused into the accumulator epilogue.
+//
+// Fused path (all dims <= 256, <= 4 layers): one workgroup of 4 waves owns 32 envs; activations ping-pong between two
+// padded LDS tiles, weights stream from L2 as one 16-byte load per lane per 4 k-steps; a wave computes 32x32 output
+// tiles. One launch per policy step. Layers that do not fit use the per-layer kernel.
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -9,24 +13,115 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// y[N,O] = act(x[N,K] W[O,K]^T + b[O]);  grid = (ceil(N/32), ceil(O/32)), block = 64
+constexpr int kTileRows = 16, kMaxDim = 256, kLd = kMaxDim + 1, kMaxLayers = 4;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Wt[k][o] = W[o][k] for k < K, 0 for K <= k < Kpad: torch.nn.Linear layout -> what the MFMA B operand wants
+// (coalesced over output units), K padded to the 64-deep chunk of the main loop so that loop needs no predicates.
+__global__ void k_transpose_pad(const float* __restrict__ W, float* __restrict__ Wt, int O, int K, int Kpad) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;   // i = k * O + o over the padded matrix (coalesced writes)
+  if (i < O * Kpad) { int k = i / O, o = i - k * O; Wt[i] = k < K ? W[(size_t)o * K + k] : 0.0f; }
+}
+
+struct MlpArgs {
+  const float* w[kMaxLayers];   // transposed + padded
+  const float* b[kMaxLayers];
+  int dims[kMaxLayers + 1];
+  int n_layers, N;
+};
+
+// One workgroup (4 waves) owns 16 envs; activations ping-pong between two padded LDS tiles. A wave computes 16x16 output
+// tiles with v_mfma_f32_16x16x4_f32 (exact f32), TWO tiles at a time so the two accumulator chains hide the 40-cycle
+// dependent latency behind the 32-cycle issue interval. Lane (r = l&15, q = l>>4) feeds A[i=r][k=k0+q], B[k=k0+q][j=r].
+__global__ void __launch_bounds__(256) k_mlp_fused(const float* __restrict__ obs, float* __restrict__ out, MlpArgs a) {
+  __shared__ float act[2][kTileRows * kLd];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int row0 = blockIdx.x * kTileRows;
+  for (int i = tid; i < 2 * kTileRows * kLd; i += 256) (&act[0][0])[i] = 0.0f;   // padded k-columns must be finite
+  __syncthreads();
+  {  // stage the observation tile (coalesced rows)
+    const int K = a.dims[0];
+    for (int i = tid; i < kTileRows * K; i += 256) {
+      int rr = i / K, kk = i - rr * K;
+      act[0][rr * kLd + kk] = (row0 + rr < a.N) ? obs[(size_t)(row0 + rr) * K + kk] : 0.0f;
+    }
+  }
+  __syncthreads();
+  for (int l = 0; l < a.n_layers; l++) {
+    const int K = a.dims[l], O = a.dims[l + 1];
+    const bool last = l == a.n_layers - 1;
+    const float* __restrict__ Wt = a.w[l];
+    const float* __restrict__ B = a.b[l];
+    const float* xrow = act[l & 1] + r * kLd;
+    float* y = act[(l + 1) & 1];
+    const int ntile = (O + 15) / 16, nch = (K + 63) >> 6;
+    for (int t = wave * 2; t < ntile; t += 8) {   // this wave: tiles t and t+1
+      const int c0 = t * 16 + r, c1 = c0 + 16;
+      const bool ok0 = c0 < O, ok1 = c1 < O;
+      const float* w0 = Wt + (ok0 ? c0 : 0);
+      const float* w1 = Wt + (ok1 ? c1 : 0);
+      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      float cur0[16], cur1[16], nx0[16], nx1[16];
+#pragma unroll
+      for (int j = 0; j < 16; j++) { cur0[j] = w0[(size_t)(4 * j + q) * O]; cur1[j] = w1[(size_t)(4 * j + q) * O]; }
+      for (int c = 0; c < nch; c++) {
+        const int kb = (c << 6) + q;
+        if (c + 1 < nch) {
+#pragma unroll
+          for (int j = 0; j < 16; j++) { nx0[j] = w0[(size_t)(kb + 64 + 4 * j) * O]; nx1[j] = w1[(size_t)(kb + 64 + 4 * j) * O]; }
+        }
+        float av[16];
+#pragma unroll
+        for (int j = 0; j < 16; j++) av[j] = xrow[kb + 4 * j];
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cur0[j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cur1[j], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; j++) { cur0[j] = nx0[j]; cur1[j] = nx1[j]; }
+      }
+      // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+      for (int half = 0; half < 2; half++) {
+        const int col = half ? c1 : c0;
+        if (half ? ok1 : ok0) {
+          const float bias = B[col];
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) {
+            const int rr = q * 4 + reg;
+            float v = (half ? acc1[reg] : acc0[reg]) + bias;
+            if (!last) {
+              v = v > 0.0f ? v : expm1f(v);
+              y[rr * kLd + col] = v;
+            } else if (row0 + rr < a.N) {
+              out[(size_t)(row0 + rr) * O + col] = v;
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// y[N,O] = act(x[N,K] W[O,K]^T + b[O]);  grid = (ceil(N/32), ceil(O/32)), block = 64   (fallback for wide layers)
 __global__ void __launch_bounds__(64) k_linear_mfma(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                     float* __restrict__ y, int N, int K, int O, int elu) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
   const int row0 = blockIdx.x * 32, col0 = blockIdx.y * 32;
-  const int ar = row0 + r, bc = col0 + r;  // A row (env), B column (output unit) owned by this lane
+  const int ar = row0 + r, bc = col0 + r;
   const bool aok = ar < N, bok = bc < O;
   const float* xa = x + (size_t)(aok ? ar : 0) * K;
   const float* wb = W + (size_t)(bok ? bc : 0) * K;
   f32x16 acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  // lane l feeds A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31] of each 32x32x2 step
   for (int k0 = 0; k0 < K; k0 += 2) {
     const int k = k0 + h;
     float a = (aok && k < K) ? xa[k] : 0.0f;
     float w = (bok && k < K) ? wb[k] : 0.0f;
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, w, acc, 0, 0, 0);
   }
-  // C/D layout: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   const int col = col0 + r;
   if (col < O) {
     const float bias = b[col];
@@ -42,11 +137,12 @@ __global__ void __launch_bounds__(64) k_linear_mfma(const float* __restrict__ x,
   }
 }
 
-static thread_local std::string g_perr;
+static float* g_wt = nullptr;   // transposed weights of the fused path (repacked every call: weights change between PPO updates)
+static size_t g_wt_n = 0;
+static int g_wt_dev = -1;
 static float* g_scratch[2] = {nullptr, nullptr};
 static size_t g_scratch_n = 0;
 static int g_scratch_dev = -1;
-extern "C" const char* nm_last_error(void);
 extern "C" int nm_policy_set_error(const char* m);
 
 extern "C" int nm_policy_forward(const float* obs, int32_t N, const float* const* weights, const float* const* bias, const int32_t* dims,
@@ -54,6 +150,30 @@ extern "C" int nm_policy_forward(const float* obs, int32_t N, const float* const
   if (!obs || !weights || !bias || !dims || !actions || N <= 0 || n_layers <= 0) return nm_policy_set_error("nm_policy_forward: bad argument");
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_forward: no HIP device");
+  bool fits = n_layers <= kMaxLayers;
+  for (int l = 0; l <= n_layers && fits; l++) fits = dims[l] > 0 && dims[l] <= kMaxDim;
+  if (fits) {
+    MlpArgs a;
+    a.n_layers = n_layers; a.N = N;
+    size_t tot = 0;
+    for (int l = 0; l < n_layers; l++) tot += (size_t)((dims[l] + 63) & ~63) * dims[l + 1];
+    if (tot > g_wt_n || dev != g_wt_dev) {
+      if (g_wt) (void)hipFree(g_wt);
+      if (hipMalloc((void**)&g_wt, tot * sizeof(float)) != hipSuccess) return nm_policy_set_error("nm_policy_forward: hipMalloc failed");
+      g_wt_n = tot; g_wt_dev = dev;
+    }
+    size_t off = 0;
+    for (int l = 0; l < n_layers; l++) {
+      int kpad = (dims[l] + 63) & ~63, n = kpad * dims[l + 1];
+      hipLaunchKernelGGL(k_transpose_pad, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights[l], g_wt + off, dims[l + 1], dims[l], kpad);
+      a.w[l] = g_wt + off; a.b[l] = bias[l];
+      off += n;
+    }
+    for (int l = 0; l <= n_layers; l++) a.dims[l] = dims[l];
+    hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(256), 0, (hipStream_t)stream, obs, actions, a);
+    if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward: launch failed");
+    return 0;
+  }
   size_t maxh = 0;
   for (int l = 1; l < n_layers; l++) maxh = (size_t)dims[l] > maxh ? (size_t)dims[l] : maxh;
   size_t need = (size_t)N * (maxh ? maxh : 1);

@@ -120,10 +120,13 @@ class NightmareV3Env:
             self.extras["time_outs"] = self.time_out_buf
 
     def step(self, actions):
-        a = actions.to(device=self.device, dtype=torch.float32)
+        a = actions
+        if a.device != self.device or a.dtype != torch.float32:
+            a = a.to(device=self.device, dtype=torch.float32)
         if a.dim() != 2 or a.shape[0] != self.num_envs or a.shape[1] < 18:
             raise ValueError(f"actions must be [{self.num_envs}, 18], got {tuple(a.shape)}")
-        a = a[:, :18].contiguous()
+        if a.shape[1] != 18 or not a.is_contiguous():
+            a = a[:, :18].contiguous()
         ep = self._eplen()
         _lib.check(self._L.nm_step(self._h, a.data_ptr(), ep.data_ptr(), self.obs_buf.data_ptr(), self.rew_buf.data_ptr(),
                                    self.reset_buf.data_ptr(), self.time_out_buf.data_ptr(), self._ep_stats.data_ptr(), self._stream()))

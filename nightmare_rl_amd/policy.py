@@ -20,18 +20,28 @@ class ActorMLP(torch.nn.Module):
                 x = torch.nn.functional.elu(x)
         return x
 
+    def _bind(self, n, device):
+        """(Re)build the cached C argument arrays: weight pointers, dims, and a persistent output buffer (stable
+        addresses, so a policy+env step can be captured in a HIP graph)."""
+        ptrs = tuple(p.data_ptr() for l in self.layers for p in (l.weight, l.bias))
+        key = (n, str(device), ptrs)
+        if getattr(self, "_key", None) != key:
+            k = len(self.layers)
+            self._w = (C.c_void_p * k)(*[l.weight.data_ptr() for l in self.layers])
+            self._b = (C.c_void_p * k)(*[l.bias.data_ptr() for l in self.layers])
+            self._dims = (C.c_int32 * (k + 1))(*self.dims)
+            self._out = torch.empty(n, self.dims[-1], device=device, dtype=torch.float32)
+            self._key = key
+
     @torch.no_grad()
     def forward(self, obs):
         L = _lib.load()
         if not obs.is_cuda:
             raise _lib.NightmareHipError("ActorMLP.forward needs a HIP tensor (no CPU path); use torch_forward on the host")
-        obs = obs.contiguous().float()
-        n = len(self.layers)
-        w = (C.c_void_p * n)(*[l.weight.data_ptr() for l in self.layers])
-        b = (C.c_void_p * n)(*[l.bias.data_ptr() for l in self.layers])
-        dims = (C.c_int32 * (n + 1))(*self.dims)
-        out = torch.empty(obs.shape[0], self.dims[-1], device=obs.device, dtype=torch.float32)
+        if obs.dtype != torch.float32 or not obs.is_contiguous():
+            obs = obs.contiguous().float()
+        self._bind(obs.shape[0], obs.device)
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        with torch.cuda.device(obs.device):
-            _lib.check(L.nm_policy_forward(obs.data_ptr(), obs.shape[0], w, b, dims, n, out.data_ptr(), stream))
-        return out
+        _lib.check(L.nm_policy_forward(obs.data_ptr(), obs.shape[0], self._w, self._b, self._dims, len(self.layers),
+                                       self._out.data_ptr(), stream))
+        return self._out
