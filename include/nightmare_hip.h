@@ -106,6 +106,11 @@ int nm_set_ablation(nm_env* env, int32_t mask);
 int nm_policy_forward(const float* obs_dev, int32_t num_envs, const float* const* weights_dev, const float* const* bias_dev,
                       const int32_t* dims, int32_t n_layers, float* actions_dev, void* stream);
 
+/* GAE(lambda) returns of one rollout (rsl_rl v1.0.2 RolloutStorage.compute_returns; caller reference train.py:54).
+ * rewards/values/returns [T,N] f32, dones [T,N] u8, last_values [N] f32, all device memory. */
+int nm_gae(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev,
+           int32_t T, int32_t N, float gamma, float lam, float* returns_dev, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

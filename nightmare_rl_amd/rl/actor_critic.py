@@ -1,0 +1,74 @@
+"""ActorCritic: separate actor / critic MLPs + a learned, state-independent action std (rsl_rl v1.0.2
+`modules/actor_critic.py` semantics; reference configuration envs/nightmare_v3_config.py:105-109). Parameter names
+(`actor.<i>.weight`, `critic.<i>.weight`, `std`) match upstream so `model_<it>.pt['model_state_dict']` checkpoints
+(reference play.py:71) load in both directions."""
+import torch
+import torch.nn as nn
+from torch.distributions import Normal
+
+_ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
+
+
+def _mlp(n_in, hidden, n_out, act):
+    dims = [n_in] + list(hidden)
+    layers = []
+    for a, b in zip(dims[:-1], dims[1:]):
+        layers += [nn.Linear(a, b), act()]
+    layers.append(nn.Linear(dims[-1], n_out))
+    return nn.Sequential(*layers)
+
+
+class ActorCritic(nn.Module):
+    is_recurrent = False
+
+    def __init__(self, num_actor_obs, num_critic_obs, num_actions, actor_hidden_dims=(256, 256, 256), critic_hidden_dims=(256, 256, 256),
+                 activation="elu", init_noise_std=1.0, **kwargs):
+        super().__init__()
+        if kwargs:
+            print("ActorCritic: ignoring unexpected arguments " + str(list(kwargs)))
+        act = _ACTIVATIONS[activation]
+        self.actor = _mlp(num_actor_obs, actor_hidden_dims, num_actions, act)
+        self.critic = _mlp(num_critic_obs, critic_hidden_dims, 1, act)
+        self.std = nn.Parameter(init_noise_std * torch.ones(num_actions))
+        self.distribution = None
+        self.actor_dims = [num_actor_obs] + list(actor_hidden_dims) + [num_actions]
+        self.activation_name = activation
+        Normal.set_default_validate_args(False)
+
+    def reset(self, dones=None):
+        pass
+
+    def forward(self):
+        raise NotImplementedError
+
+    @property
+    def action_mean(self):
+        return self.distribution.mean
+
+    @property
+    def action_std(self):
+        return self.distribution.stddev
+
+    @property
+    def entropy(self):
+        return self.distribution.entropy().sum(dim=-1)
+
+    def update_distribution(self, observations):
+        mean = self.actor(observations)
+        self.distribution = Normal(mean, mean * 0.0 + self.std)
+
+    def act(self, observations, **kwargs):
+        self.update_distribution(observations)
+        return self.distribution.sample()
+
+    def get_actions_log_prob(self, actions):
+        return self.distribution.log_prob(actions).sum(dim=-1)
+
+    def act_inference(self, observations):
+        return self.actor(observations)
+
+    def evaluate(self, critic_observations, **kwargs):
+        return self.critic(critic_observations)
+
+    def actor_linears(self):
+        return [m for m in self.actor if isinstance(m, nn.Linear)]

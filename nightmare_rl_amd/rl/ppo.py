@@ -1,0 +1,118 @@
+"""PPO: clipped surrogate + clipped value loss, entropy bonus, adaptive-KL learning rate, Adam, grad-norm clipping
+(rsl_rl v1.0.2 `algorithms/ppo.py` semantics; reference hyper-parameters envs/nightmare_v3_config.py:111-128).
+With torch.distributed initialised, gradients are averaged across ranks with one flat all-reduce per mini-batch and
+the KL used for the learning-rate schedule is the global mean, so every rank takes identical steps."""
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+import torch.optim as optim
+
+from .storage import RolloutStorage
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class PPO:
+    def __init__(self, actor_critic, num_learning_epochs=1, num_mini_batches=1, clip_param=0.2, gamma=0.998, lam=0.95,
+                 value_loss_coef=1.0, entropy_coef=0.0, learning_rate=1e-3, max_grad_norm=1.0, use_clipped_value_loss=True,
+                 schedule="fixed", desired_kl=0.01, device="cpu"):
+        self.device = device
+        self.desired_kl, self.schedule, self.learning_rate = desired_kl, schedule, learning_rate
+        self.actor_critic = actor_critic.to(device)
+        self.storage = None
+        self.optimizer = optim.Adam(self.actor_critic.parameters(), lr=learning_rate)
+        self.transition = RolloutStorage.Transition()
+        self.clip_param, self.num_learning_epochs, self.num_mini_batches = clip_param, num_learning_epochs, num_mini_batches
+        self.value_loss_coef, self.entropy_coef = value_loss_coef, entropy_coef
+        self.gamma, self.lam, self.max_grad_norm, self.use_clipped_value_loss = gamma, lam, max_grad_norm, use_clipped_value_loss
+
+    def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
+        self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
+
+    def test_mode(self):
+        self.actor_critic.eval()
+
+    def train_mode(self):
+        self.actor_critic.train()
+
+    def act(self, obs, critic_obs):
+        t = self.transition
+        t.actions = self.actor_critic.act(obs).detach()
+        t.values = self.actor_critic.evaluate(critic_obs).detach()
+        t.actions_log_prob = self.actor_critic.get_actions_log_prob(t.actions).detach()
+        t.action_mean = self.actor_critic.action_mean.detach()
+        t.action_sigma = self.actor_critic.action_std.detach()
+        t.observations, t.critic_observations = obs, critic_obs
+        return t.actions
+
+    def process_env_step(self, rewards, dones, infos):
+        t = self.transition
+        t.rewards = rewards.clone()
+        t.dones = dones
+        if "time_outs" in infos:   # bootstrap the value of envs that merely ran out of time
+            t.rewards += self.gamma * torch.squeeze(t.values * infos["time_outs"].unsqueeze(1).to(self.device), 1)
+        self.storage.add_transitions(t)
+        t.clear()
+        self.actor_critic.reset(dones)
+
+    def compute_returns(self, last_critic_obs):
+        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        self.storage.compute_returns(last_values, self.gamma, self.lam)
+
+    def _sync_grads(self):
+        if _world() == 1:
+            return
+        grads = [p.grad for p in self.actor_critic.parameters() if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat)
+        flat /= _world()
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n
+
+    def update(self):
+        v_sum = torch.zeros((), device=self.device)
+        s_sum = torch.zeros((), device=self.device)
+        gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
+        for (obs, cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in gen:
+            self.actor_critic.act(obs)
+            logp = self.actor_critic.get_actions_log_prob(actions)
+            value = self.actor_critic.evaluate(cobs)
+            mu, sigma, entropy = self.actor_critic.action_mean, self.actor_critic.action_std, self.actor_critic.entropy
+            if self.desired_kl is not None and self.schedule == "adaptive":
+                with torch.inference_mode():
+                    kl = torch.sum(torch.log(sigma / old_sigma + 1.0e-5) + (old_sigma.square() + (old_mu - mu).square()) / (2.0 * sigma.square()) - 0.5, dim=-1)
+                    kl_mean = kl.mean()
+                    if _world() > 1:
+                        dist.all_reduce(kl_mean)
+                        kl_mean /= _world()
+                    kl_mean = float(kl_mean)   # the one host sync per mini-batch the schedule needs
+                if kl_mean > self.desired_kl * 2.0:
+                    self.learning_rate = max(1e-5, self.learning_rate / 1.5)
+                elif 0.0 < kl_mean < self.desired_kl / 2.0:
+                    self.learning_rate = min(1e-2, self.learning_rate * 1.5)
+                for g in self.optimizer.param_groups:
+                    g["lr"] = self.learning_rate
+            adv = advantages.squeeze(-1)
+            ratio = torch.exp(logp - old_logp.squeeze(-1))
+            surrogate_loss = torch.max(-adv * ratio, -adv * ratio.clamp(1.0 - self.clip_param, 1.0 + self.clip_param)).mean()
+            if self.use_clipped_value_loss:
+                v_clip = target_values + (value - target_values).clamp(-self.clip_param, self.clip_param)
+                value_loss = torch.max((value - returns).square(), (v_clip - returns).square()).mean()
+            else:
+                value_loss = (returns - value).square().mean()
+            loss = surrogate_loss + self.value_loss_coef * value_loss - self.entropy_coef * entropy.mean()
+            self.optimizer.zero_grad()
+            loss.backward()
+            self._sync_grads()
+            nn.utils.clip_grad_norm_(self.actor_critic.parameters(), self.max_grad_norm)
+            self.optimizer.step()
+            v_sum += value_loss.detach()
+            s_sum += surrogate_loss.detach()
+        n = self.num_learning_epochs * self.num_mini_batches
+        self.storage.clear()
+        return float(v_sum / n), float(s_sum / n)

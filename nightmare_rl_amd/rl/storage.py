@@ -1,0 +1,91 @@
+"""RolloutStorage: [steps, envs, ...] buffers resident on the device; GAE(lambda) returns; shuffled mini-batches
+(rsl_rl v1.0.2 `storage/rollout_storage.py` semantics). The backward GAE scan runs in one HIP kernel (nm_gae) on a
+GPU and in torch on the host (tests)."""
+import ctypes as C
+
+import torch
+
+from ..distributed import global_advantage_stats
+
+
+class RolloutStorage:
+    class Transition:
+        def __init__(self):
+            self.clear()
+
+        def clear(self):
+            self.observations = self.critic_observations = self.actions = self.rewards = self.dones = None
+            self.values = self.actions_log_prob = self.action_mean = self.action_sigma = None
+
+    def __init__(self, num_envs, num_transitions_per_env, obs_shape, privileged_obs_shape, actions_shape, device="cpu"):
+        self.device = device
+        self.num_envs, self.num_transitions_per_env = num_envs, num_transitions_per_env
+        T, N = num_transitions_per_env, num_envs
+        z = lambda *s: torch.zeros(T, N, *s, device=device)
+        self.observations = z(*obs_shape)
+        self.privileged_observations = z(*privileged_obs_shape) if privileged_obs_shape and privileged_obs_shape[0] is not None else None
+        self.rewards, self.values, self.returns, self.advantages, self.actions_log_prob = z(1), z(1), z(1), z(1), z(1)
+        self.actions, self.mu, self.sigma = z(*actions_shape), z(*actions_shape), z(*actions_shape)
+        self.dones = torch.zeros(T, N, 1, device=device, dtype=torch.uint8)
+        self.step = 0
+
+    def add_transitions(self, t):
+        if self.step >= self.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        s = self.step
+        self.observations[s].copy_(t.observations)
+        if self.privileged_observations is not None:
+            self.privileged_observations[s].copy_(t.critic_observations)
+        self.actions[s].copy_(t.actions)
+        self.rewards[s].copy_(t.rewards.view(-1, 1))
+        self.dones[s].copy_(t.dones.view(-1, 1))
+        self.values[s].copy_(t.values)
+        self.actions_log_prob[s].copy_(t.actions_log_prob.view(-1, 1))
+        self.mu[s].copy_(t.action_mean)
+        self.sigma[s].copy_(t.action_sigma)
+        self.step += 1
+
+    def clear(self):
+        self.step = 0
+
+    def compute_returns(self, last_values, gamma, lam):
+        if self.rewards.is_cuda:
+            from .. import _lib
+            L = _lib.load()
+            T, N = self.num_transitions_per_env, self.num_envs
+            stream = C.c_void_p(torch.cuda.current_stream(self.rewards.device).cuda_stream)
+            lv = last_values.contiguous().view(-1).float()
+            with torch.cuda.device(self.rewards.device):
+                _lib.check(L.nm_gae(self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(), lv.data_ptr(), T, N,
+                                    float(gamma), float(lam), self.returns.data_ptr(), stream))
+        else:
+            adv = torch.zeros_like(last_values)
+            for s in reversed(range(self.num_transitions_per_env)):
+                nxt = last_values if s == self.num_transitions_per_env - 1 else self.values[s + 1]
+                live = 1.0 - self.dones[s].float()
+                delta = self.rewards[s] + live * gamma * nxt - self.values[s]
+                adv = delta + live * gamma * lam * adv
+                self.returns[s] = adv + self.values[s]
+        self.advantages = self.returns - self.values
+        mean, std = global_advantage_stats(self.advantages)   # over ALL ranks' envs x steps
+        self.advantages = (self.advantages - mean) / (std + 1e-8)
+
+    def get_statistics(self):
+        done = self.dones.clone()
+        done[-1] = 1
+        flat = done.permute(1, 0, 2).reshape(-1, 1)
+        idx = torch.cat((flat.new_tensor([-1], dtype=torch.int64), flat.nonzero(as_tuple=False)[:, 0]))
+        lengths = idx[1:] - idx[:-1]
+        return lengths.float().mean(), self.rewards.mean()
+
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        B = self.num_envs * self.num_transitions_per_env
+        mb = B // num_mini_batches
+        idx = torch.randperm(num_mini_batches * mb, device=self.device)
+        obs = self.observations.flatten(0, 1)
+        cobs = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else obs
+        flat = [t.flatten(0, 1) for t in (self.actions, self.values, self.advantages, self.returns, self.actions_log_prob, self.mu, self.sigma)]
+        for _ in range(num_epochs):
+            for i in range(num_mini_batches):
+                b = idx[i * mb:(i + 1) * mb]
+                yield (obs[b], cobs[b]) + tuple(t[b] for t in flat) + ((None, None), None)

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""train.py - the reference's training entry point (reference train.py:1-54) on the MI355X backend.
+Same flags (-r resume, -v render [rejected: no viewer], -n num_threads [accepted, unused], -e envs, -p resume_path) plus
+--iters / --seed. Multi-GPU: python -m torch.distributed.run --nproc-per-node G train.py -e <total envs>."""
+import argparse
+import datetime
+import os
+
+import torch
+
+from nightmare_rl_amd.distributed import shard_range
+from nightmare_rl_amd.envs.helpers import class_to_dict, get_load_path
+from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config, NightmareV3ConfigPPO
+from nightmare_rl_amd.envs.nightmare_v3_env import NightmareV3Env
+from nightmare_rl_amd.rl import OnPolicyRunner
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("-r", "--resume", action="store_true", default=False, dest="resume")
+    ap.add_argument("-v", "--render", action="store_true", default=False, dest="render")
+    ap.add_argument("-n", "--num_threads", type=int, default=1, dest="num_threads")
+    ap.add_argument("-e", "--envs", type=int, default=2048, dest="num_envs")
+    ap.add_argument("-p", "--resume_path", type=str, default=None, dest="resume_path")
+    ap.add_argument("--iters", type=int, default=None, help="learning iterations (default: cfg.runner.max_iterations)")
+    ap.add_argument("--seed", type=int, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    log_root = "logs/nightmare_v3/"
+    log_dir = f"logs/nightmare_v3/{datetime.datetime.now()}/"
+    cfg, train_cfg = NightmareV3Config(), NightmareV3ConfigPPO()
+    cfg.viewer.render = args.render
+    lo, hi = shard_range(args.num_envs, rank, world)
+    cfg.env.num_envs = hi - lo
+    train_cfg.runner.resume = args.resume
+    seed = train_cfg.seed if args.seed is None else args.seed
+    torch.manual_seed(seed + rank)
+    env = NightmareV3Env(cfg, log_dir=log_dir, num_threads=args.num_threads, device=f"cuda:{local_rank}", seed=seed, env_id_offset=lo)
+    runner = OnPolicyRunner(env, class_to_dict(train_cfg), log_dir=log_dir, device=f"cuda:{local_rank}")
+    if train_cfg.runner.resume:
+        path = get_load_path(args.resume_path or log_root, load_run=train_cfg.runner.load_run, checkpoint=train_cfg.runner.checkpoint)
+        print(f"Loading model from: {path}")
+        runner.load(path)
+    runner.learn(num_learning_iterations=args.iters if args.iters is not None else train_cfg.runner.max_iterations, init_at_random_ep_len=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
