@@ -111,6 +111,26 @@ int nm_policy_forward(const float* obs_dev, int32_t num_envs, const float* const
 int nm_gae(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev,
            int32_t T, int32_t N, float gamma, float lam, float* returns_dev, void* stream);
 
+/* ---- scripted gait / IK engine (reference nikengine/engine.py; caller custom_play.py:49-76), batched over envs ----
+ * One handle = num_envs independent EngineNode objects (engine.py:660-677), all in IdleState. */
+typedef struct nm_nik nm_nik;
+nm_nik* nm_nik_create(int32_t num_envs, int32_t device);
+void nm_nik_destroy(nm_nik* h);
+/* back to IdleState with the default pose (a fresh EngineNode). ids_host NULL = all envs. */
+int nm_nik_reset(nm_nik* h, const int32_t* ids_host, int32_t n, void* stream);
+/* EngineNode.update(lin_speed, ang_speed, state, mode) (engine.py:710-715) for every env, one launch.
+ *   lin_dev, ang_dev [N] f64 device: walk translation along +y (m/s) and yaw rate (rad/s) commands
+ *   awake_dev, walk_dev [N] u8 device or NULL: state == 'awake' (else 'idle'), mode == 'walk' (else 'stand'); NULL = 1
+ *   now_s: the engine clock (set_time_s, engine.py:12-19); engine_fps: config.ENGINE_FPS, read every tick like upstream
+ *   angles_f32_dev / angles_f64_dev [N,18] device, either may be NULL: the 18 joint targets set_hardware_pose returns
+ *   (IK + SERVO_OFFSET + URDF_JOINT_OFFSETS, engine.py:700-708). Arithmetic is f64. */
+int nm_nik_update(nm_nik* h, const double* lin_dev, const double* ang_dev, const unsigned char* awake_dev,
+                  const unsigned char* walk_dev, double now_s, double engine_fps, float* angles_f32_dev,
+                  double* angles_f64_dev, void* stream);
+/* FSM inspection for tests: HOST pose [N,18] (foot positions in the body frame), fsm id [N]
+ * (0 idle 1 adjust-get-up 2 get-up 3 sit 4 adjust-sit 5 stand 6 walk), gait_step_state [N]. NULL = skip. Synchronous. */
+int nm_nik_get_state(nm_nik* h, double* pose_host, int32_t* fsm_host, double* gait_step_state_host);
+
 #ifdef __cplusplus
 }
 #endif
