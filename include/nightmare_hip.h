@@ -92,6 +92,19 @@ int nm_get_counters(nm_env* env, int64_t* out3);
 /* optional debug dump [N,256] reals (dtype of the env) written by nm_step; NULL disables */
 int nm_set_debug_buffer(nm_env* env, void* dbg_dev);
 
+/* Observation noise (envs/nightmare_v3_env.py:109-119 builds noise_scale_vec, :304-305 applies it): with a HOST [66] vector
+ * set, every nm_step adds (2u-1)*noise_scale_vec[k] to observation k before the clip, u ~ U[0,1) from the counter RNG
+ * keyed by (seed, global env id, step, k). NULL switches it off (the default, config add_noise=False :49). */
+int nm_set_observation_noise(nm_env* env, const double* noise_scale_vec_host);
+/* RNG-free noise for parity tests: HOST [N,66] uniforms used by the following steps instead of the counter RNG
+ * (what np.random.rand(N,66) returned at :305). NULL = RNG. */
+int nm_set_noise_uniforms(nm_env* env, const double* u_host);
+/* State log (envs/nightmare_v3_env.py:261-272 records data[0]): env_index >= 0 makes every nm_step keep that env's
+ * post-physics, pre-reset qpos/qvel; -1 = off. nm_get_state_record copies the last record to HOST qpos[25], qvel[24] and
+ * the number of MuJoCo bad-state resets inside that step (data.time restarts there). Synchronous. */
+int nm_set_state_record(nm_env* env, int32_t env_index);
+int nm_get_state_record(nm_env* env, double* qpos, double* qvel, int32_t* bad_state_resets);
+
 /* Measurement hook (no reference counterpart): when enabled, every nm_step / nm_step_physics brackets its step
  * kernel with HIP events on the launch stream. Each call synchronises, returns the summed kernel time and the
  * launch count since the previous call, clears them, and sets the new enable state. */

@@ -88,7 +88,15 @@ template <class real> struct Args {
   int nsub;              // decimation
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
   int ablate;            // measurement only: bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage
+  // observation noise (env.py:109-119,304-305): null = off
+  const real* noise_vec; // [66] noise_scale_vec
+  const real* noise_u;   // [N,66] injected uniforms (parity tests) or null = counter RNG
+  uint64_t noise_step;   // step index of this launch (RNG counter = noise_step*66 + k)
+  // state log of one env (env.py:261-272): post-physics, pre-reset qpos[25] qvel[24] + bad-state-reset count; null = off
+  real* rec;
+  int rec_env;
 };
+constexpr uint64_t kNoiseKey = 0x4E4F495345ull;
 constexpr int kDbgN = 256;
 
 // ----------------------------------------------------------------------------------------- LDS image of one env
@@ -1556,6 +1564,11 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
   gstv(A.qpos, lane + env * kNQ, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
   gstv(A.qvel, lane + env * kNV, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
   gstv(A.qwarm, lane + env * kNV, ldsv(sh.warm, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
+  if (A.rec && env == A.rec_env) {
+    gstv(A.rec, lane, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
+    gstv(A.rec, lane + kNQ, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
+    gstv(A.rec, V<int>(kNQ + kNV), to_real<real>(sh.nwarn), lane == 0);
+  }
   if (A.dbg) {
     real* dbg = A.dbg + (size_t)env * kDbgN;
     gstv(dbg, lane, ldsv(sh.qas, sel(lane < 24, lane, V<int>(0))), lane < 24);
@@ -1694,7 +1707,20 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     vr o = vr(real(0));
 #pragma unroll
     for (int k = 0; k < 12; k++) o = wrlane(o, head[k], k);
-    auto put = [&](const vr& x, const V<int>& idx, const VB& m) {
+    auto put = [&](const vr& x0, const V<int>& idx, const VB& m) {
+      vr x = x0;
+      if (A.noise_vec) {  // env.py:304-305: + (2 U[0,1) - 1) * noise_scale_vec before the clip
+        auto nz = [&](int k) {
+          real u = A.noise_u ? A.noise_u[(size_t)env * kNOBS + k]
+                             : (real)rand_u24_bits(A.seed + kNoiseKey, (uint64_t)(A.env_offset + env), (uint32_t)(A.noise_step * kNOBS + k)) * real(1.0 / 16777216.0);
+          return (real(2) * u - real(1)) * A.noise_vec[k];
+        };
+#ifdef NM_EMUL
+        for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) x.v[i] = x.v[i] + nz(idx.v[i]);
+#else
+        if (m) x = x + nz(idx);
+#endif
+      }
       vr cx = vmin(vmax(x, vr(-M.clip_obs)), vr(M.clip_obs));
 #ifdef NM_EMUL
       for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) A.obs[(size_t)env * kNOBS + idx.v[i]] = (float)cx.v[i];

@@ -103,6 +103,10 @@ struct nm_env {
   virtual void set_dbg(void* p) = 0;
   virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
   virtual void set_ablate(int m) = 0;
+  virtual int set_noise(const double* vec) = 0;
+  virtual int set_noise_u(const double* u) = 0;
+  virtual int set_record(int idx) = 0;
+  virtual int get_record(double* qpos, double* qvel, int32_t* nbad) = 0;
 };
 
 template <class real> struct Env : nm_env {
@@ -116,6 +120,12 @@ template <class real> struct Env : nm_env {
   int32_t* ids_dev = nullptr;
   long long* counters_dev = nullptr;
   nm::Model<real>* M_dev = nullptr;
+  real* noise_vec_dev = nullptr;
+  real* noise_u_dev = nullptr;
+  bool noise_on = false, noise_u_on = false;
+  uint64_t noise_step = 0;
+  real* rec_dev = nullptr;
+  int rec_env = -1;
   bool prof_on = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
@@ -194,6 +204,13 @@ template <class real> struct Env : nm_env {
     a.actions = actions; a.eplen = eplen; a.obs = obs; a.rew = rew; a.done = done; a.timeout_now = timeout_now;
     a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
     a.physics_only = physics_only;
+    if (!physics_only) {
+      a.noise_vec = noise_on ? noise_vec_dev : nullptr;
+      a.noise_u = noise_on && noise_u_on ? noise_u_dev : nullptr;
+      a.noise_step = noise_step++;
+      a.rec = rec_env >= 0 ? rec_dev : nullptr;
+      a.rec_env = rec_env;
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (prof_on) {  // HIP events on the launch stream around the dominant kernel only (bench.py's roofline leg)
       if (prof_used == prof_ev.size()) {
@@ -260,6 +277,39 @@ template <class real> struct Env : nm_env {
     long long c[3];
     HIPCHK(hipMemcpy(c, counters_dev, sizeof c, hipMemcpyDeviceToHost));
     out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    return 0;
+  }
+  int set_noise(const double* vec) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    noise_on = vec != nullptr;
+    if (vec && !noise_vec_dev && dalloc(&noise_vec_dev, NM_NUM_OBS)) return 1;
+    return vec ? h2d(noise_vec_dev, vec, NM_NUM_OBS) : 0;
+  }
+  int set_noise_u(const double* u) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    noise_u_on = u != nullptr;
+    if (u && !noise_u_dev && dalloc(&noise_u_dev, (size_t)N * NM_NUM_OBS)) return 1;
+    return u ? h2d(noise_u_dev, u, (size_t)N * NM_NUM_OBS) : 0;
+  }
+  int set_record(int idx) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    if (idx >= N) return fail("nm_set_state_record: env index out of range");
+    if (idx >= 0 && !rec_dev && dalloc(&rec_dev, 64)) return 1;
+    rec_env = idx < 0 ? -1 : idx;
+    return 0;
+  }
+  int get_record(double* qpos, double* qvel, int32_t* nbad) override {
+    HIPCHK(hipSetDevice(device));
+    if (rec_env < 0) return fail("nm_get_state_record: recording is off (nm_set_state_record)");
+    HIPCHK(hipDeviceSynchronize());
+    double tmp[50];
+    if (d2h(rec_dev, tmp, 50)) return 1;
+    if (qpos) for (int i = 0; i < 25; i++) qpos[i] = tmp[i];
+    if (qvel) for (int i = 0; i < 24; i++) qvel[i] = tmp[25 + i];
+    if (nbad) *nbad = (int32_t)tmp[49];
     return 0;
   }
   void set_dbg(void* p) override { A.dbg = (real*)p; }
@@ -352,5 +402,9 @@ int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return en
 int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
 int nm_set_ablation(nm_env* env, int32_t mask) { NEED(env); env->set_ablate(mask); return 0; }
+int nm_set_observation_noise(nm_env* env, const double* vec) { NEED(env); return env->set_noise(vec); }
+int nm_set_noise_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_noise_u(u); }
+int nm_set_state_record(nm_env* env, int32_t idx) { NEED(env); return env->set_record(idx); }
+int nm_get_state_record(nm_env* env, double* qpos, double* qvel, int32_t* nbad) { NEED(env); return env->get_record(qpos, qvel, nbad); }
 int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count) { NEED(env); return env->profiling(enable, sum_ms, count); }
 }

@@ -6,9 +6,15 @@ Differences a caller can observe (all documented in DESIGN.md):
   * returned tensors are views of persistent device buffers, valid until the next step() (the reference returns
     fresh CPU tensors, :311)
   * commands come from a counter-based generator keyed by (seed, global env id) instead of numpy's global RNG (:327-330)
-  * no viewer / state recording (`cfg.viewer.*` must be False)
+  * no viewer (`cfg.viewer.render` must be False); `cfg.viewer.record_states` writes the reference's pickle log (:261-272)
+    at the price of one device sync per step
+  * observation noise (`cfg.noise.add_noise`, :304-305) draws from the same counter generator; `cfg.noise.layout`
+    chooses between the reference's noise_scale_vec (written for a 12-dof robot, :113-119) and the 18-dof one
 """
 import ctypes as C
+import os
+import pickle
+import time
 
 import numpy as np
 import torch
@@ -30,10 +36,8 @@ class NightmareV3Env:
         self.num_actions = int(cfg.env.num_actions)
         if self.num_obs != _lib.NUM_OBS or self.num_actions != _lib.NUM_ACTIONS:
             raise ValueError("the compiled path is specialised for num_obs=66, num_actions=18")
-        if cfg.viewer.render or cfg.viewer.record_states:
-            raise ValueError("cfg.viewer.render / record_states are not available on the GPU path (set them to False)")
-        if cfg.noise.add_noise:
-            raise NotImplementedError("observation noise (reference :304-305) is not on the compiled path yet")
+        if cfg.viewer.render:
+            raise ValueError("cfg.viewer.render is not available on the GPU path (set it to False)")
         if cfg.env.tibia_contact_mode != 1 or cfg.env.body_contact_mode != 1:
             raise NotImplementedError("only tibia/body_contact_mode == 1 (the reference default) is compiled")
         if not torch.cuda.is_available():
@@ -101,6 +105,52 @@ class NightmareV3Env:
         self._stat_names = names
         self.extras = {}
         self.common_step_counter = 0
+        # observation noise (reference :109-119, :304-305)
+        self.noise_scale_vec = self._noise_scale_vec(cfg)
+        self.add_noise = bool(cfg.noise.add_noise)
+        if self.add_noise:
+            _lib.check(L.nm_set_observation_noise(h, self.noise_scale_vec.ctypes.data_as(C.c_void_p)))
+        # state log of env 0 (reference :261-272; reader open_custom_play.py:50-66)
+        self.recorded_states = []
+        self._rec_time = 0.0
+        if cfg.viewer.record_states:
+            _lib.check(L.nm_set_state_record(h, 0))
+
+    def _noise_scale_vec(self, cfg):
+        ns, lvl, osc = cfg.noise.noise_scales, cfg.noise.noise_level, self.obs_scales
+        v = np.zeros(self.num_obs)
+        v[:3] = ns.lin_vel * lvl * osc.lin_vel
+        v[3:6] = ns.ang_vel * lvl * osc.ang_vel
+        v[6:9] = ns.gravity * lvl
+        layout = getattr(cfg.noise, "layout", "reference")
+        if layout == "reference":       # the upstream index ranges, kept verbatim (they assume 12 dofs)
+            v[12:24] = ns.dof_pos * lvl * osc.dof_pos
+            v[24:36] = ns.dof_vel * lvl * osc.dof_vel
+        elif layout == "dof18":         # the ranges of this robot's observation (E8: dof_pos 12:30, dof_vel 30:48)
+            v[12:30] = ns.dof_pos * lvl * osc.dof_pos
+            v[30:48] = ns.dof_vel * lvl * osc.dof_vel
+        else:
+            raise ValueError("cfg.noise.layout must be 'reference' or 'dof18'")
+        return v
+
+    def set_noise_uniforms(self, u=None):
+        """RNG-free noise for parity tests: [N,66] uniforms in [0,1) used instead of the generator (None = generator)."""
+        u = None if u is None else np.ascontiguousarray(u, np.float64).reshape(self.num_envs, self.num_obs)
+        _lib.check(self._L.nm_set_noise_uniforms(self._h, None if u is None else u.ctypes.data_as(C.c_void_p)))
+
+    def _record_state(self):
+        # reference :261-272: when env 0 resets, dump what was logged so far, then log (time, qpos, qvel, act) of env 0
+        # as it is after the physics and before reset_idx. This model has no actuator state: act is empty.
+        qpos, qvel, nbad = np.empty(25), np.empty(24), C.c_int32(0)
+        _lib.check(self._L.nm_get_state_record(self._h, qpos.ctypes.data_as(C.c_void_p), qvel.ctypes.data_as(C.c_void_p), C.byref(nbad)))
+        if bool(self.reset_buf[0].item()):
+            os.makedirs(self.log_dir, exist_ok=True)
+            with open(f"{self.log_dir}/{int(time.time())}.pkl", "wb") as f:
+                pickle.dump(self.recorded_states, f)
+            self.recorded_states = []
+        sim_dt = 0.008 * self.cfg.control.decimation
+        self._rec_time = sim_dt if nbad.value else self._rec_time + sim_dt   # mj_resetData restarts data.time
+        self.recorded_states.append((self._rec_time, qpos, qvel, np.zeros(0)))
 
     # ------------------------------------------------------------------ reference surface
     def _stream(self):
@@ -132,6 +182,8 @@ class NightmareV3Env:
                                    self.reset_buf.data_ptr(), self.time_out_buf.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
         self._last_actions = a  # keep the input alive until the kernel has read it
         self.common_step_counter += 1
+        if self.cfg.viewer.record_states:
+            self._record_state()
         if "episode" not in self.extras:
             self._fill_extras()
         return self.obs_buf, None, self.rew_buf, self.reset_buf, self.extras

@@ -79,6 +79,10 @@ void nmo_env_reset_idx(nmo_env* e, const int32_t* ids, int n, const double* cmd_
  * resample, (x,yaw) for the reset resample; NULL -> internal counter RNG. Outputs may be NULL. */
 void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done,
                   float* time_outs, double* obs64, double* rew64);
+/* observation noise: noise_scale_vec66 NULL = off; u = injected [N,66] uniforms for the next steps or NULL = counter RNG
+ * keyed (seed + NMO_NOISE_KEY, global env id, step*66 + k) */
+#define NMO_NOISE_KEY 0x4E4F495345ull
+void nmo_env_set_noise(nmo_env* e, const double* noise_scale_vec66, const double* u);
 void nmo_env_get_state(nmo_env* e, double* qpos, double* qvel, double* qacc_warmstart);
 void nmo_env_set_state(nmo_env* e, const double* qpos, const double* qvel, const double* qacc_warmstart);
 /* host-side buffers the reference keeps between steps: dof_pos, dof_vel (stale across resets), actions, commands,

@@ -53,6 +53,11 @@ struct nmo_env {
   uint8_t* time_out;
   double ep_stats[NMO_NREW];
   int last_nreset;
+  /* observation noise (env.py:109-119,304-305) */
+  int noise_on;
+  double noise_vec[66];
+  double* noise_u; /* [N,66] injected uniforms (tests) or NULL = counter RNG */
+  uint64_t noise_step;
 };
 
 double nmo_rand_u24(uint64_t seed, uint64_t genv, uint32_t ctr) {
@@ -95,7 +100,7 @@ void nmo_env_destroy(nmo_env* e) {
   if (!e) return;
   free(e->data); free(e->scratch); free(e->dof_pos); free(e->dof_vel); free(e->commands); free(e->episode_sums);
   free(e->actions); free(e->prev_actions); free(e->ep_len); free(e->rng_ctr); free(e->blv); free(e->bav); free(e->pg);
-  free(e->tibia); free(e->feet); free(e->body); free(e->rew_terms); free(e->reset_buf); free(e->time_out);
+  free(e->tibia); free(e->feet); free(e->body); free(e->rew_terms); free(e->reset_buf); free(e->time_out); free(e->noise_u);
   free(e);
 }
 nmo_data* nmo_env_data(nmo_env* e, int i) { return &e->data[i]; }
@@ -273,6 +278,12 @@ void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* 
       o[30 + j] = e->dof_vel[i * 18 + j] * OBS_DOF_VEL;
       o[48 + j] = (double)e->actions[i * 18 + j];
     }
+    if (e->noise_on) /* env.py:304-305: obs += (2 U[0,1) - 1) * noise_scale_vec, before the clip */
+      for (int k = 0; k < 66; k++) {
+        double u = e->noise_u ? e->noise_u[i * 66 + k]
+                              : nmo_rand_u24(e->seed + NMO_NOISE_KEY, (uint64_t)(e->env_off + i), (uint32_t)(e->noise_step * 66 + k));
+        o[k] += (2.0 * u - 1.0) * e->noise_vec[k];
+      }
     for (int k = 0; k < 66; k++) {
       double x = o[k] < -CLIP_OBS ? -CLIP_OBS : (o[k] > CLIP_OBS ? CLIP_OBS : o[k]);
       if (obs) obs[i * 66 + k] = (float)x;
@@ -282,6 +293,18 @@ void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* 
     if (time_outs) time_outs[i] = (float)e->time_out[i];
   }
   free(prev_dof_vel);
+  e->noise_step++;
+}
+
+void nmo_env_set_noise(nmo_env* e, const double* noise_scale_vec66, const double* u) {
+  e->noise_on = noise_scale_vec66 != NULL;
+  if (noise_scale_vec66) memcpy(e->noise_vec, noise_scale_vec66, sizeof e->noise_vec);
+  free(e->noise_u);
+  e->noise_u = NULL;
+  if (u) {
+    e->noise_u = (double*)malloc(sizeof(double) * e->N * 66);
+    memcpy(e->noise_u, u, sizeof(double) * e->N * 66);
+  }
 }
 
 void nmo_env_get_state(nmo_env* e, double* qpos, double* qvel, double* qw) {

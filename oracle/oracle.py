@@ -87,6 +87,7 @@ def lib():
         L.nmo_env_destroy.argtypes = [C.c_void_p]
         L.nmo_env_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.nmo_env_step.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        L.nmo_env_set_noise.argtypes = [C.c_void_p] * 3
         L.nmo_env_get_state.argtypes = [C.c_void_p] * 4
         L.nmo_env_set_state.argtypes = [C.c_void_p] * 4
         L.nmo_env_get_buffers.argtypes = [C.c_void_p] * 7
@@ -173,6 +174,11 @@ class OracleEnv:
         self.L.nmo_env_step(self.h, _ptr(a), _ptr(cu), _ptr(obs), _ptr(rew), _ptr(done), _ptr(to), _ptr(obs64), _ptr(rew64))
         self.obs64, self.rew64 = obs64, rew64
         return obs, rew, done, to
+
+    def set_noise(self, noise_scale_vec=None, u=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+        vec, u = f(noise_scale_vec), f(u)
+        self.L.nmo_env_set_noise(self.h, _ptr(vec), _ptr(u))
 
     def reset(self):
         self.reset_idx()

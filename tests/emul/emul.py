@@ -32,6 +32,8 @@ def lib():
         L.emu_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int] + [C.c_void_p] * 3
         L.emu_get.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.emu_set_noise.argtypes = [C.c_void_p] * 3
+        L.emu_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_eplen.argtypes = [C.c_void_p]
         L.emu_eplen.restype = C.POINTER(C.c_int64)
         _lib = L
@@ -66,6 +68,17 @@ class EmulEnv:
         w, k = WHAT[name]
         v = np.ascontiguousarray(val, np.float64).reshape(self.N, k)
         self.L.emu_set(self.h, w, _p(v))
+
+    def set_noise(self, vec=None, u=None):
+        f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
+        vec, u = f(vec), f(u)
+        self.L.emu_set_noise(self.h, _p(vec), _p(u))
+
+    def record(self, env):
+        """Select the env whose pre-reset state is logged; returns the last record (qpos25, qvel24, nbad)."""
+        out = np.zeros(50)
+        self.L.emu_record(self.h, env, _p(out))
+        return out[:25], out[25:49], int(out[49])
 
     @property
     def eplen(self):

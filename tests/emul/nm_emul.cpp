@@ -17,6 +17,8 @@ struct EmuBase {
   virtual void get(int what, double* out) = 0;
   virtual void set(int what, const double* in) = 0;
   virtual int64_t* eplen() = 0;
+  virtual void set_noise(const double* vec, const double* u) = 0;
+  virtual void record(int env, double* out50) = 0;
 };
 
 template <class real> struct Emu : EmuBase {
@@ -30,6 +32,18 @@ template <class real> struct Emu : EmuBase {
   uint64_t seed;
   int64_t off;
   int G = 1;
+  std::vector<real> nvec, nu, rec = std::vector<real>(64, 0);
+  uint64_t nstep = 0;
+  int rec_env = -1;
+  void set_noise(const double* vec, const double* u) override {
+    nvec.clear(); nu.clear();
+    if (vec) nvec.assign(vec, vec + 66);
+    if (u) nu.assign(u, u + (size_t)N * 66);
+  }
+  void record(int env, double* out50) override {
+    rec_env = env;
+    if (out50) for (int i = 0; i < 50; i++) out50[i] = (double)rec[i];
+  }
   Emu(int n, uint64_t s, int64_t o, int g) : N(n), seed(s), off(o), G(g) {
     T.build();
     nmhost::EnvConfig cfg;
@@ -64,6 +78,10 @@ template <class real> struct Emu : EmuBase {
     A.actions = actions; A.cmd_u = cmd_u ? cu.data() : nullptr;
     A.obs = obs; A.rew = rew; A.timeout_now = to; A.done = done; A.stat_sum = ssum.data(); A.stat_cnt = scnt;
     A.dbg = dbg ? dbgr.data() : nullptr; A.nsub = nsub; A.physics_only = physics_only;
+    if (!physics_only) {
+      A.noise_vec = nvec.empty() ? nullptr : nvec.data(); A.noise_u = nu.empty() ? nullptr : nu.data(); A.noise_step = nstep++;
+      A.rec = rec_env >= 0 ? rec.data() : nullptr; A.rec_env = rec_env;
+    }
     if (G == 1) {
       static thread_local nm::ShW<real, 1> sh;
       for (int wv = 0; wv < N; wv++) nm::wave_step<real, 1>(sh, M, A, wv);
@@ -91,5 +109,7 @@ void emu_step(void* h, const float* actions, const double* cmd_u, float* obs, fl
 void emu_get(void* h, int what, double* out) { ((EmuBase*)h)->get(what, out); }
 void emu_set(void* h, int what, const double* in) { ((EmuBase*)h)->set(what, in); }
 int64_t* emu_eplen(void* h) { return ((EmuBase*)h)->eplen(); }
+void emu_set_noise(void* h, const double* vec, const double* u) { ((EmuBase*)h)->set_noise(vec, u); }
+void emu_record(void* h, int env, double* out50) { ((EmuBase*)h)->record(env, out50); }
 int emu_dbg_n() { return nm::kDbgN; }
 }

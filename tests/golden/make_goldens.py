@@ -123,7 +123,7 @@ class RandRecorder:
         np.random.rand = self._orig
 
 
-def run_scenario(name, N, steps, seed, setup=None, action_fn=None):
+def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False):
     import torch
     from envs.nightmare_v3_config import NightmareV3Config
     from envs.nightmare_v3_env import NightmareV3Env
@@ -132,12 +132,13 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None):
     cfg.env.num_envs = N
     cfg.viewer.render = False
     cfg.viewer.record_states = False
+    cfg.noise.add_noise = noise
     np.random.seed(seed)
     env = NightmareV3Env(cfg, log_dir="/tmp/nm_golden_logs", num_threads=1)
     rng = np.random.default_rng(seed + 1000)
     log = {k: [] for k in ("actions", "obs", "rew", "done", "time_outs", "commands", "ep_len", "cmd_u", "qpos", "qvel", "qacc_warmstart",
                            "base_lin_vel", "base_ang_vel", "projected_gravity", "tibia", "feet", "body", "dof_pos", "dof_vel",
-                           "episode_sums", "ep_stats", "nreset")}
+                           "episode_sums", "ep_stats", "nreset", "noise_u")}
     # reset() = reset_idx(all) + step(zeros)   (env.py:392-396)
     with RandRecorder() as rr:
         env.reset_idx(np.arange(N))
@@ -156,6 +157,10 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None):
         ep_before = env.episode_length_buf.numpy().copy()
         with RandRecorder() as rr:
             obs, _, rew, done, extras = env.step(torch.tensor(a))
+        noise_calls = [c for c in rr.calls if np.ndim(c) == 2]          # np.random.rand(N, 66) at env.py:305
+        rr.calls = [c for c in rr.calls if np.ndim(c) != 2]
+        assert len(noise_calls) == (1 if noise else 0)
+        log["noise_u"].append(noise_calls[0] if noise else np.zeros((0, 66)))
         # reconstruct which envs drew what: periodic resample first (always called), then reset_idx (only if any reset)
         cu = np.full((N, 4), 0.5)
         per_ids = np.nonzero((ep_before + 1) % 625 == 0)[0]
@@ -241,5 +246,17 @@ def main():
                  action_fn=lambda t, rng, N: rng.uniform(-1, 1, (N, 18)).astype(np.float32) * 3.0)
 
 
+def main_noise():
+    """(d) observation noise on (cfg.noise.add_noise): the uniforms np.random.rand returned are part of the fixture."""
+    install_stub()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    run_scenario("noise", N=5, steps=40, seed=4, noise=True,
+                 action_fn=lambda t, rng, N: rng.uniform(-1, 1, (N, 18)).astype(np.float32) * 2.0)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "noise":
+        main_noise()
+    else:
+        main()

@@ -6,7 +6,7 @@ import pytest
 
 from conftest import load_golden
 
-SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz"]
+SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz", "env_noise.npz"]
 
 
 def teacher_forced(make_env, g, steps=None):
@@ -21,6 +21,8 @@ def teacher_forced(make_env, g, steps=None):
         e.set("qpos", qpos); e.set("qvel", qvel); e.set("qwarm", qw); e.set("dofpos", dofpos); e.set("dofvel", dofvel)
         e.set("cmd", cmd); e.set("act", act)
         e.eplen[:] = ep
+        if "noise_u" in g and g["noise_u"].shape[1] > 0:
+            e.set_noise(g["noise_scale_vec"], g["noise_u"][t])
         obs, rew, done, to = e.step(g["actions"][t], cmd_u=g["cmd_u"][t])
         oerr.append(np.abs(obs.astype(np.float64) - g["obs"][t]).max(axis=1))
         rerr.append(np.abs(rew.astype(np.float64) - g["rew"][t]))
@@ -105,3 +107,53 @@ def test_envs_per_wave_does_not_change_results(emul):
         for x, y in zip(o1, o2):
             np.testing.assert_array_equal(x, y)
     np.testing.assert_array_equal(e1.get("qpos"), e2.get("qpos"))
+
+
+def test_noise_generator_matches_oracle(emul, oracle_mod):
+    """Counter-RNG observation noise (no injected uniforms): device algorithm == oracle, keyed by global env id and step."""
+    N, off = 4, 1000
+    vec = np.linspace(0.01, 0.5, 66)
+    e = emul.EmulEnv(N, double=True, seed=7, env_off=off)
+    o = oracle_mod.OracleEnv(N, seed=7, env_id_offset=off)
+    o.reset_idx(None)
+    e.set("cmd", o.get_buffers()["commands"])
+    e.set_noise(vec)
+    o.set_noise(vec)
+    rng = np.random.default_rng(0)
+    clean = None
+    for t in range(6):
+        a = rng.uniform(-1, 1, (N, 18)).astype(np.float32)
+        obs_e = e.step(a)[0]
+        obs_o = o.step(a)[0]
+        np.testing.assert_allclose(obs_e, obs_o, atol=2e-7)
+    o2 = oracle_mod.OracleEnv(N, seed=7, env_id_offset=off)     # same run without noise: the difference is the noise
+    o2.reset_idx(None)
+    rng = np.random.default_rng(0)
+    for t in range(6):
+        clean = o2.step(rng.uniform(-1, 1, (N, 18)).astype(np.float32))[0]
+    d = (obs_o - clean) / vec
+    assert np.abs(d).max() <= 1.0 + 1e-5 and np.abs(d).std() > 0.2
+
+
+def test_state_record_is_the_pre_reset_state(emul):
+    """env.py:261-272 logs data[0] after the physics and before reset_idx."""
+    g = load_golden("env_falls.npz")
+    N = g["actions"].shape[1]
+    for env_i in (1, 2):
+        e = emul.EmulEnv(N, double=True)
+        e.record(env_i)
+        e.set("qpos", g["init_qpos"]); e.set("qvel", g["init_qvel"]); e.set("qwarm", g["init_qacc_warmstart"])
+        e.set("dofpos", g["init_dof_pos"]); e.set("dofvel", g["init_dof_vel"]); e.set("cmd", g["init_commands"])
+        e.eplen[:] = g["init_ep_len"]
+        seen_reset = False
+        for t in range(g["actions"].shape[0]):
+            _, _, done, _ = e.step(g["actions"][t], cmd_u=g["cmd_u"][t])
+            qpos, qvel, nbad = e.record(env_i)
+            if done[env_i]:
+                seen_reset = True
+                assert np.abs(e.get("qvel")[env_i]).max() == 0 and np.abs(qvel).max() > 0      # log has the terminal state
+            else:
+                np.testing.assert_allclose(qpos, e.get("qpos")[env_i], atol=0)
+                np.testing.assert_allclose(qvel, e.get("qvel")[env_i], atol=0)
+            assert nbad == 0
+        assert seen_reset

@@ -5,7 +5,7 @@ import pytest
 
 from conftest import load_golden
 
-SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz"]
+SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz", "env_noise.npz"]
 
 
 def replay(orc, g, check):
@@ -14,7 +14,10 @@ def replay(orc, g, check):
     env.reset_idx(None, cmd_u=g["reset_u"])
     env.set_state(g["init_qpos"], g["init_qvel"], g["init_qacc_warmstart"])
     env.set_buffers(dof_pos=g["init_dof_pos"], dof_vel=g["init_dof_vel"], commands=g["init_commands"], ep_len=g["init_ep_len"])
+    noisy = "noise_u" in g and g["noise_u"].shape[1] > 0
     for t in range(g["actions"].shape[0]):
+        if noisy:   # the uniforms np.random.rand(N, 66) returned inside the reference step (env.py:305)
+            env.set_noise(g["noise_scale_vec"], g["noise_u"][t])
         obs, rew, done, to = env.step(g["actions"][t], cmd_u=g["cmd_u"][t])
         check(t, env, obs, rew, done, to)
     return env
@@ -56,6 +59,13 @@ def test_reference_constants(oracle_mod):
     assert abs(float(g["dt"]) - 0.016) < 1e-15
     scales = dict(zip(g["reward_names"], g["reward_scales"]))
     assert abs(scales["termination"] + 3.2) < 1e-12 and abs(scales["tracking_lin_vel"] - 0.128) < 1e-12
+
+
+def test_noise_fixture_is_noisy_and_uses_the_upstream_index_ranges():
+    g = load_golden("env_noise.npz")
+    v = g["noise_scale_vec"]
+    assert v.shape == (66,) and (v[12:36] > 0).all() and (v[36:] == 0).all() and (v[9:12] == 0).all()   # env.py:113-119
+    assert g["noise_u"].shape[1:] == (5, 66) and 0 <= g["noise_u"].min() and g["noise_u"].max() < 1
 
 
 def test_golden_covers_edge_cases():
