@@ -188,6 +188,15 @@ class NightmareV3Env:
             self._fill_extras()
         return self.obs_buf, None, self.rew_buf, self.reset_buf, self.extras
 
+    def actions_from_joint_targets(self, targets):
+        """Policy-space actions that make the servo track absolute joint targets (the hook at reference :186):
+        step() commands (action_scale*a - default_pos - dof_pos)*p_gain (:152-156,:183-188), so a = (q* + default_pos)/action_scale.
+        Targets beyond clip_actions - default_pos saturate, as any action does."""
+        d = getattr(self, "_default_t", None)
+        if d is None:
+            d = self._default_t = torch.as_tensor(self.default_dof_pos, dtype=torch.float32, device=self.device)
+        return (targets.to(device=self.device, dtype=torch.float32) + d) / float(self.cfg.control.action_scale)
+
     def step_physics(self, actions):
         """mj_step x decimation only (no rewards/obs/reset): the 'dynamics+contact kernel' configuration."""
         a = actions.to(device=self.device, dtype=torch.float32)[:, :18].contiguous()

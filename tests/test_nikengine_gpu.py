@@ -79,3 +79,20 @@ def test_float32_output_and_errors():
         e.reset(np.array([9]))
     with pytest.raises(_lib.NightmareHipError):
         nk.EngineNode(1, device="cpu")
+
+
+def test_gait_engine_walks_the_simulated_robot():
+    """custom_play.py:49-76 end to end on the device: gait kernel -> rate limit -> env servo -> rigid-body/contact kernel.
+    The robot must get up to the stand height and cover about 0.2 m/s x walking time without any termination."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "scripts"))
+    from custom_play import play
+    from nightmare_rl_amd import nikengine as nk
+    r = play(num_envs=32, seconds=10.0, lin=0.05, ang=0.0)
+    nk.config.ENGINE_FPS = 51.0
+    dist = np.linalg.norm(r["displacement"][:, :2], axis=1)
+    assert r["falls"] == 0
+    assert (r["fsm"] == 6).all()
+    assert 0.07 < r["height"].min() and r["height"].max() < 0.13, (r["height"].min(), r["height"].max())
+    assert 0.6 < dist.min() and dist.max() < 1.5, (dist.min(), dist.max())       # 5.5 s of walking at ~0.2 m/s
