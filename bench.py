@@ -81,8 +81,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # NM_DIST_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (ranks then share devices)
+        backend = os.environ.get("NM_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank %= max(torch.cuda.device_count(), 1)
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend)
         dist.barrier()
     else:
         torch.cuda.set_device(local_rank)
@@ -192,7 +199,7 @@ def main():
             "closed_loop_mlp_2x256_env_steps_per_s": closed,
             "counters": env.counters(),
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline()
     if world > 1:
         dist.barrier()
