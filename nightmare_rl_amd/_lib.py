@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "libnightmare_hip.so")
+LIB_PATH = os.environ.get("NM_HIP_LIB") or os.path.join(HERE, "csrc", "libnightmare_hip.so")   # NM_HIP_LIB: measurement builds
 NUM_OBS, NUM_ACTIONS, NUM_REWARDS = 66, 18, 8
 DTYPE_F32, DTYPE_F64 = 0, 1
 

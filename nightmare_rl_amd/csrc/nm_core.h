@@ -126,7 +126,7 @@ template <class real> struct Sh {
 // constraints and the env epilogue take the envs one after the other on all 64 lanes) + one shared row buffer.
 template <class real, int G> struct ShW {
   Sh<real> e[G];
-  real jrow[kMaxRow * kJRow];
+  alignas(16) real jrow[kMaxRow * kJRow];
 };
 #define NM_OFS(field) ((int)(offsetof(Sh<real>, field) / sizeof(real)))
 
@@ -264,6 +264,24 @@ NM_FN uint32_t rand_u24_bits(uint64_t seed, uint64_t genv, uint32_t ctr) {
   x ^= x >> 31;
   return (uint32_t)(x >> 40);
 }
+
+// Optional in-kernel stage timing (build with -DNM_STAMPS; measurement builds only, never the shipped library):
+// lane 0 of every wave adds the s_memtime ticks since its previous stamp to g_stamps[k].
+#if defined(NM_STAMPS) && !defined(NM_EMUL)
+__device__ unsigned long long g_stamps[16];
+NM_FN void nm_stamp(int k) {   // k = -1 starts the clock, k = 10 is the last stamp of a wave and flushes its sums
+  __shared__ unsigned long long tl, acc[16];
+  unsigned long long n = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) {
+    if (k < 0) for (int i = 0; i < 16; i++) acc[i] = 0;
+    else acc[k] += n - tl;
+    if (k == 10) for (int i = 0; i <= 10; i++) atomicAdd(&g_stamps[i], acc[i]);
+    tl = n;
+  }
+}
+#else
+NM_FN void nm_stamp(int) {}
+#endif
 
 // =========================================================================================  stage A
 // Everything "smooth": kinematics, inertia blocks + both factorisations, bias, servo forces, qacc_smooth - for all G
@@ -995,7 +1013,9 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
   sh.ncon = ncon;
   sh.anypair = 0;
   wave_sync();
+  nm_stamp(3);
   if (pairs) stage_collide_pairs(sh, M, dropped);
+  nm_stamp(4);
 }
 
 // =========================================================================================  stage C
@@ -1027,12 +1047,13 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   if (anypair) L1 = ldsv(sh.cleg1, c);
   const VB onleg1 = L1 >= 0;
   const V<int> Lc1 = vmax(L1, V<int>(0));
-  // pyramid edge direction d = n +- mu t_k; floor frame n=(0,0,1), t1=(0,1,0), t2=(-1,0,0) (mju_makeFrame)
+  // Contact frame (mju_makeFrame): floor contacts have n=(0,0,1), t1=(0,1,0), t2=(-1,0,0). Lane q of a contact's quad first
+  // builds the Jacobian row of ONE frame axis (q: n, t1, t2, n) and publishes it for the projection sweep; its own pyramid
+  // row is then J(n) +- mu J(t_k) (mj_instantiateContact's formula), fetched from the quad by DPP.
+  const V<int> q4 = lane & 3;
   vr smu = sel(sg == 0, vr(M.mu), vr(-M.mu));
-  vr d[3], nrm[3] = {vr(real(0)), vr(real(0)), vr(real(1))};
-  d[0] = sel(tk == 1, -smu, vr(real(0)));
-  d[1] = sel(tk == 0, smu, vr(real(0)));
-  d[2] = vr(real(1));
+  vr nrm[3] = {vr(real(0)), vr(real(0)), vr(real(1))};
+  vr e[3] = {sel(q4 == 2, vr(real(-1)), vr(real(0))), sel(q4 == 1, vr(real(1)), vr(real(0))), sel((q4 == 0) | (q4 == 3), vr(real(1)), vr(real(0)))};
   if (anypair) {
     nrm[0] = ldsv(sh.cnrm, c * 3); nrm[1] = ldsv(sh.cnrm, c * 3 + 1); nrm[2] = ldsv(sh.cnrm, c * 3 + 2);
     VB usey = (nrm[1] < vr(real(0.5))) & (nrm[1] > vr(real(-0.5)));
@@ -1043,16 +1064,16 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     t1[0] = t1[0] * il; t1[1] = t1[1] * il; t1[2] = t1[2] * il;
     cross3(t2, nrm, t1);
 #pragma unroll
-    for (int j = 0; j < 3; j++) d[j] = nrm[j] + smu * sel(tk == 0, t1[j], t2[j]);
+    for (int j = 0; j < 3; j++) e[j] = sel(q4 == 1, t1[j], sel(q4 == 2, t2[j], nrm[j]));
   }
-  // Jacobian row: base translation, base rotation (body axes), the 3 hinges of the contact's own leg
-  vr Jb[6], Jl[3];
+  // frame-axis Jacobian row: base translation, base rotation (body axes), the 3 hinges of the contact's own leg
+  vr Fb[6], Fl[3], Fm[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
   {
     vr m[3];
-    cross3(m, cp, d);  // (p - O) x d
-    Jb[0] = d[0]; Jb[1] = d[1]; Jb[2] = d[2];
+    cross3(m, cp, e);  // (p - O) x e
+    Fb[0] = e[0]; Fb[1] = e[1]; Fb[2] = e[2];
 #pragma unroll
-    for (int j = 0; j < 3; j++) Jb[3 + j] = sh.Rb[j] * m[0] + sh.Rb[3 + j] * m[1] + sh.Rb[6 + j] * m[2];
+    for (int j = 0; j < 3; j++) Fb[3 + j] = sh.Rb[j] * m[0] + sh.Rb[3 + j] * m[1] + sh.Rb[6 + j] * m[2];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       vr a[3], r[3], rel[3], mm[3];
@@ -1062,12 +1083,11 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
         r[j] = ldsv(sh.anc, Lc * 9 + (3 * k + j));
         rel[j] = cp[j] - r[j];
       }
-      cross3(mm, rel, d);
-      Jl[k] = sel(onleg, dot3<vr>(a, mm), vr(real(0)));
+      cross3(mm, rel, e);
+      Fl[k] = sel(onleg, dot3<vr>(a, mm), vr(real(0)));
     }
   }
-  vr Jm[3] = {vr(real(0)), vr(real(0)), vr(real(0))};  // body1 side: -J(body1); the base columns of J(b2) - J(b1) cancel exactly
-  if (anypair) {
+  if (anypair) {  // body1 side: -J(body1); the base columns of J(b2) - J(b1) cancel exactly
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       vr a[3], r[3], rel[3], mm[3];
@@ -1077,34 +1097,49 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
         r[j] = ldsv(sh.anc, Lc1 * 9 + (3 * k + j));
         rel[j] = cp[j] - r[j];
       }
-      cross3(mm, rel, d);
-      Jm[k] = sel(onleg1 & act, -dot3<vr>(a, mm), vr(real(0)));
+      cross3(mm, rel, e);
+      Fm[k] = sel(onleg1 & act, -dot3<vr>(a, mm), vr(real(0)));
     }
 #pragma unroll
-    for (int j = 0; j < 6; j++) Jb[j] = sel(onleg1, vr(real(0)), Jb[j]);
+    for (int j = 0; j < 6; j++) Fb[j] = sel(onleg1, vr(real(0)), Fb[j]);
   }
 #pragma unroll
-  for (int j = 0; j < 6; j++) Jb[j] = sel(act, Jb[j], vr(real(0)));
+  for (int j = 0; j < 6; j++) Fb[j] = sel(act, Fb[j], vr(real(0)));
 #pragma unroll
-  for (int k = 0; k < 3; k++) Jl[k] = sel(act, Jl[k], vr(real(0)));
-  // publish the sparse row for the projection sweep
+  for (int k = 0; k < 3; k++) Fl[k] = sel(act, Fl[k], vr(real(0)));
+  // publish the frame rows (rows 4c, 4c+1, 4c+2 of the buffer = n, t1, t2 of contact c) for the projection sweep
 #pragma unroll
-  for (int j = 0; j < 6; j++) stsv(jrow, lane * kJRow + j, Jb[j], lane < kMaxRow);
+  for (int j = 0; j < 6; j++) stsv(jrow, lane * kJRow + j, Fb[j], lane < kMaxRow);
 #pragma unroll
-  for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (6 + k), Jl[k], lane < kMaxRow);
-  stsv(jrow, lane * kJRow + 9, to_real<real>(L), lane < kMaxRow);
+  for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (6 + k), Fl[k], lane < kMaxRow);
   if (anypair) {
 #pragma unroll
-    for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (10 + k), Jm[k], lane < kMaxRow);
-    stsv(jrow, lane * kJRow + 13, to_real<real>(L1), lane < kMaxRow);
+    for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (10 + k), Fm[k], lane < kMaxRow);
+  }
+  // own pyramid row J = J(n) + smu J(t_k): quad lane 0 holds n, lanes 1 / 2 hold t1 / t2
+  vr Jb[6], Jl[3], Jm[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
+#pragma unroll
+  for (int j = 0; j < 6; j++) Jb[j] = quad<0x00>(Fb[j]) + smu * quad<0xA5>(Fb[j]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) Jl[k] = quad<0x00>(Fl[k]) + smu * quad<0xA5>(Fl[k]);
+  if (anypair) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) Jm[k] = quad<0x00>(Fm[k]) + smu * quad<0xA5>(Fm[k]);
   }
 
   // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
   vr imp;
   {
     vr x = vabs(dist) / M.si_width;
-    vr ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
-    vr yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
+    vr ylo, yhi;
+    if (M.si_power == real(2)) {  // the model's solimp (mjmodel.xml defaults): pow(x, 2) = x*x and pow(mid, 1) = mid, both exact
+      vr omx = vmax(vr(real(1)) - x, vr(real(0)));
+      ylo = (x * x) / M.si_mid;
+      yhi = vr(real(1)) - (omx * omx) / (real(1) - M.si_mid);
+    } else {
+      ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
+      yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
+    }
     vr y = sel(x <= vr(M.si_mid), ylo, yhi);
     imp = M.si_d0 + y * (M.si_dmax - M.si_d0);
     imp = sel(x >= vr(real(1)), vr(M.si_dmax), imp);
@@ -1175,37 +1210,50 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       }
   }
   wave_sync();
-  // A[i] (in lane j) = J_i . B_j  -> lane j holds row j of the symmetric A = J M^-1 J'
+  // A[i] (in lane j) = J_i . B_j  -> lane j holds row j of the symmetric A = J M^-1 J'. Per contact: the three frame rows
+  // are read once (wave-uniform LDS reads), dotted with this lane's B, and combined into the four pyramid rows
+  // (n +- mu t1, n +- mu t2). The leg block of B is re-selected only when the contact's leg changes (contacts come grouped
+  // by mesh), so the sweep has no per-row branches.
   vr A[kMaxRow];
 #pragma unroll
-  for (int i = 0; i < kMaxRow; i++) {
-    A[i] = vr(real(0));
-    if (i < nefc) {
-      const real* jr = jrow + i * kJRow;
-      vr a = jr[0] * B[0] + jr[1] * B[1] + jr[2] * B[2] + jr[3] * B[3] + jr[4] * B[4] + jr[5] * B[5];
-      const int Li = uniform((int)jr[9]);
-      switch (Li) {
-        case 0: a += jr[6] * B[6] + jr[7] * B[7] + jr[8] * B[8]; break;
-        case 1: a += jr[6] * B[9] + jr[7] * B[10] + jr[8] * B[11]; break;
-        case 2: a += jr[6] * B[12] + jr[7] * B[13] + jr[8] * B[14]; break;
-        case 3: a += jr[6] * B[15] + jr[7] * B[16] + jr[8] * B[17]; break;
-        case 4: a += jr[6] * B[18] + jr[7] * B[19] + jr[8] * B[20]; break;
-        case 5: a += jr[6] * B[21] + jr[7] * B[22] + jr[8] * B[23]; break;
-        default: break;
+  for (int i = 0; i < kMaxRow; i++) A[i] = vr(real(0));
+  {
+    vr Bs[3] = {vr(real(0)), vr(real(0)), vr(real(0))}, Bs1[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
+    int Lprev = -2, L1prev = -2;
+    auto pick = [&](vr* o, int l) {
+      switch (l) {
+        case 0: o[0] = B[6]; o[1] = B[7]; o[2] = B[8]; break;
+        case 1: o[0] = B[9]; o[1] = B[10]; o[2] = B[11]; break;
+        case 2: o[0] = B[12]; o[1] = B[13]; o[2] = B[14]; break;
+        case 3: o[0] = B[15]; o[1] = B[16]; o[2] = B[17]; break;
+        case 4: o[0] = B[18]; o[1] = B[19]; o[2] = B[20]; break;
+        case 5: o[0] = B[21]; o[1] = B[22]; o[2] = B[23]; break;
+        default: o[0] = vr(real(0)); o[1] = vr(real(0)); o[2] = vr(real(0)); break;
       }
-      if (anypair) {
-        const int L1i = uniform((int)jr[13]);
-        switch (L1i) {
-          case 0: a += jr[10] * B[6] + jr[11] * B[7] + jr[12] * B[8]; break;
-          case 1: a += jr[10] * B[9] + jr[11] * B[10] + jr[12] * B[11]; break;
-          case 2: a += jr[10] * B[12] + jr[11] * B[13] + jr[12] * B[14]; break;
-          case 3: a += jr[10] * B[15] + jr[11] * B[16] + jr[12] * B[17]; break;
-          case 4: a += jr[10] * B[18] + jr[11] * B[19] + jr[12] * B[20]; break;
-          case 5: a += jr[10] * B[21] + jr[11] * B[22] + jr[12] * B[23]; break;
-          default: break;
+    };
+#pragma unroll
+    for (int cc = 0; cc < kMaxCon; cc++) {
+      if (cc < ncon) {
+        const int Lcc = uniform(sh.cleg[cc]);
+        if (Lcc != Lprev) { pick(Bs, Lcc); Lprev = Lcc; }
+        if (anypair) {
+          const int L1cc = uniform(sh.cleg1[cc]);
+          if (L1cc != L1prev) { pick(Bs1, L1cc); L1prev = L1cc; }
         }
+        vr a3[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const real* jr = jrow + (4 * cc + r) * kJRow;
+          vr a = jr[0] * B[0] + jr[1] * B[1] + jr[2] * B[2] + jr[3] * B[3] + jr[4] * B[4] + jr[5] * B[5];
+          a += jr[6] * Bs[0] + jr[7] * Bs[1] + jr[8] * Bs[2];
+          if (anypair) a += jr[10] * Bs1[0] + jr[11] * Bs1[1] + jr[12] * Bs1[2];
+          a3[r] = a;
+        }
+        A[4 * cc] = a3[0] + M.mu * a3[1];
+        A[4 * cc + 1] = a3[0] - M.mu * a3[1];
+        A[4 * cc + 2] = a3[0] + M.mu * a3[2];
+        A[4 * cc + 3] = a3[0] - M.mu * a3[2];
       }
-      A[i] = a;
     }
   }
   // own diagonal entry (needed as 1/AR_ii): A_jj = J_j . B_j
@@ -1218,6 +1266,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr ARjj = Ajj + Rr;
   vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
 
+  nm_stamp(5);
   // ---- warm start (PGS branch of mj_fwdConstraint): f from qacc_warmstart, kept only if its dual cost < 0
   vr jar = jaw - aref;
   vr f = sel(act & (jar < vr(real(0))), -Dd * jar, vr(real(0)));
@@ -1236,60 +1285,84 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   // Per row: all lanes evaluate their own candidate, lane i's delta is broadcast (v_readlane) and applied.
   const vr hA = real(0.5) * ARjj;
   for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
-    vr impv = vr(real(0));  // per-lane improvement: lane i adds its own row's cost change
+    // A row's update is decided by its own lane at its own step: the lane keeps (delta, cost change) and applies them to
+    // f after the sweep; the other lanes only need the delta, which reaches them through g.
+    vr dcap = vr(real(0)), ccap = vr(real(0));
     const V<int> lv = opaque_lane();
 #pragma unroll
-    for (int i = 0; i < kMaxRow; i++) {
-      if (i < nefc) {
-        vr res = g + Rr * f;
-        vr fn = vmax(f - res * ARinv, vr(real(0)));
-        vr dl = fn - f;
-        vr change = dl * (hA * dl + res);          // 0.5 dl^2 AR_ii + dl res
-        VB bad = change > vr(real(1e-10));         // costChange: revert an update that does not decrease the cost
-        dl = sel(bad, vr(real(0)), dl);
-        change = sel(bad, vr(real(0)), change);
-        g += A[i] * rdlane(dl, i);
-        VB me = lv == i;
-        f = sel(me, f + dl, f);
-        impv = sel(me, impv - change, impv);
-      }
-    }
-    sh.it_pgs = iter + 1;
-    if (wsum<real>(impv) * M.pgs_scale < M.pgs_tol) break;
-  }
-  // ---- mj_solNoSlip: per opposing pyramid pair, exact 1-D minimisation along (f0 - f1) without R
-  for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
-    real improvement = real(0);
-    if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
-    const V<int> lv = opaque_lane();
+    for (int cc = 0; cc < kMaxCon; cc++) {
+      if (cc < ncon) {
 #pragma unroll
-    for (int p = 0; p < kMaxRow / 2; p++) {
-      if (2 * p < nefc) {
-        const int j0 = 2 * p, j1 = 2 * p + 1;
-        real Ac0 = rdlane(A[j0], j0), Ac1 = rdlane(A[j1], j0), Ac3 = rdlane(A[j1], j1);
-        real r0 = rdlane(g, j0), r1 = rdlane(g, j1), o0 = rdlane(f, j0), o1 = rdlane(f, j1);
-        real bc0 = r0 - Ac0 * o0 - Ac1 * o1, bc1 = r1 - Ac1 * o0 - Ac3 * o1;
-        real mid = real(0.5) * (o0 + o1);
-        real K1 = Ac0 + Ac3 - Ac1 - Ac1, K0 = mid * (Ac0 - Ac3) + bc0 - bc1;
-        real n0, n1;
-        if (K1 < real(1e-15)) { n0 = mid; n1 = mid; }
-        else {
-          real y = -K0 / K1;
-          if (y < -mid) { n0 = real(0); n1 = real(2) * mid; }
-          else if (y > mid) { n0 = real(2) * mid; n1 = real(0); }
-          else { n0 = mid + y; n1 = mid - y; }
+        for (int r = 0; r < 4; r++) {
+          const int i = 4 * cc + r;
+          vr res = g + Rr * f;
+          vr fn = vmax(f - res * ARinv, vr(real(0)));
+          vr dl = fn - f;
+          vr change = dl * (hA * dl + res);          // 0.5 dl^2 AR_ii + dl res
+          VB bad = change > vr(real(1e-10));         // costChange: revert an update that does not decrease the cost
+          dl = sel(bad, vr(real(0)), dl);
+          g += A[i] * rdlane(dl, i);
+          VB me = lv == i;
+          dcap = sel(me, dl, dcap);
+          ccap = sel(me & !bad, change, ccap);
         }
-        real d0 = n0 - o0, d1 = n1 - o1;
-        real change = real(0.5) * (d0 * (Ac0 * d0 + Ac1 * d1) + d1 * (Ac1 * d0 + Ac3 * d1)) + d0 * r0 + d1 * r1;
-        if (change > real(1e-10)) { d0 = real(0); d1 = real(0); change = real(0); }
-        improvement = improvement - change;
-        g += A[j0] * d0 + A[j1] * d1;
-        f = sel(lv == j0, vr(o0 + d0), sel(lv == j1, vr(o1 + d1), f));
       }
     }
-    sh.it_noslip = iter + 1;
-    if (improvement * M.pgs_scale < M.noslip_tol) break;
+    f = f + dcap;
+    sh.it_pgs = iter + 1;
+    if (-wsum<real>(ccap) * M.pgs_scale < M.pgs_tol) break;
   }
+  nm_stamp(6);
+  // ---- mj_solNoSlip: per opposing pyramid pair (lanes 2p, 2p+1), exact 1-D minimisation along (f0 - f1) without R.
+  // Both lanes of a pair evaluate the update from their own side ("m" = mine, "q" = the partner, fetched by DPP): the new
+  // values are mid +- y with y clamped to [-mid, mid], which is mj_solNoSlip's three-way case split. What does not change
+  // between iterations (the pair's 2x2 block of A, 1/K1) is prepared once.
+  {
+    const V<int> lv = opaque_lane();
+    const V<int> lvp = lv >> 1;
+    const VB even = (lv & 1) == 0;
+    vr Amq = vr(real(0));  // A[2p][2p+1], the even lane's copy in both lanes
+#pragma unroll
+    for (int p = 0; p < kMaxRow / 2; p++)
+      if (2 * p < nefc) Amq = sel(lv == 2 * p, A[2 * p + 1], Amq);
+    Amq = sel(even, Amq, shfl_xor1(Amq));
+    const vr Amm = Ajj, Aqq = shfl_xor1(Ajj);
+    const vr K1 = Amm + Aqq - Amq - Amq;
+    const VB small = K1 < vr(real(1e-15));
+    const vr invK1 = vr(real(1)) / K1;
+    const vr dA = Amm - Aqq;
+    for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
+      real improvement = real(0);
+      if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
+      vr dcap = vr(real(0)), ccap = vr(real(0));
+#pragma unroll
+      for (int p = 0; p < kMaxRow / 2; p++) {
+        if (2 * p < nefc) {
+          const vr oq = shfl_xor1(f), rq = shfl_xor1(g);
+          const vr bcm = g - Amm * f - Amq * oq, bcq = rq - Amq * f - Aqq * oq;
+          const vr mid = real(0.5) * (f + oq);
+          const vr K0 = mid * dA + bcm - bcq;
+          vr y = vmin(vmax(-K0 * invK1, -mid), mid);
+          y = sel(small, vr(real(0)), y);
+          vr d = (mid + y) - f;
+          const vr dq = shfl_xor1(d);
+          const vr hm = d * (real(0.5) * (Amm * d + Amq * dq) + g);   // this lane's share of the cost change
+          const vr change = hm + shfl_xor1(hm);
+          const VB bad = change > vr(real(1e-10));
+          d = sel(bad, vr(real(0)), d);
+          g += A[2 * p] * rdlane(d, 2 * p) + A[2 * p + 1] * rdlane(d, 2 * p + 1);
+          const VB me = lvp == p;
+          dcap = sel(me, d, dcap);
+          ccap = sel(me & even & !bad, change, ccap);
+        }
+      }
+      f = f + dcap;
+      improvement = improvement - wsum<real>(ccap);
+      sh.it_noslip = iter + 1;
+      if (improvement * M.pgs_scale < M.noslip_tol) break;
+    }
+  }
+  nm_stamp(7);
   stsv(sh.efc_f, lane, f, lane < kMaxRow);
   // ---- qfrc_constraint = J' f
 #pragma unroll
@@ -1497,14 +1570,18 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
     }
   }
   wave_sync();
+  nm_stamp(1);
   if (!(ablate & 8)) stage_smooth(w, M, last);
+  nm_stamp(2);
   for (int e = 0; e < G; e++) {
     Sh<real>& sh = w.e[e];
     if (!(ablate & 1)) stage_collide(sh, M, dropped, !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     if (ablate & 4) { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     stage_constraint(sh, w.jrow, M, last, (ablate & 2) != 0);
+    nm_stamp(8);
   }
   stage_integrate(w, M);
+  nm_stamp(9);
 }
 
 // =========================================================================================  env step
@@ -1758,11 +1835,13 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 // one wavefront = G consecutive envs (E2, env.py:200: mj_step(model, data, decimation) between load and epilogue)
 template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave) {
   EnvRegs<real> rg[G];
+  nm_stamp(-1);
 #pragma unroll
   for (int e = 0; e < G; e++) {
     int env = wave * G + e;
     env_load(w.e[e], M, A, env < A.N ? env : A.N - 1, rg[e]);
   }
+  nm_stamp(0);
   int dropped = 0;
   for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, A.ablate);
 #pragma unroll
@@ -1770,6 +1849,7 @@ template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<r
     int env = wave * G + e;
     env_finish(w.e[e], M, A, env, rg[e], e == 0 ? dropped : 0, env < A.N);
   }
+  nm_stamp(10);
 }
 
 }  // namespace nm

@@ -406,5 +406,14 @@ int nm_set_observation_noise(nm_env* env, const double* vec) { NEED(env); return
 int nm_set_noise_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_noise_u(u); }
 int nm_set_state_record(nm_env* env, int32_t idx) { NEED(env); return env->set_record(idx); }
 int nm_get_state_record(nm_env* env, double* qpos, double* qvel, int32_t* nbad) { NEED(env); return env->get_record(qpos, qvel, nbad); }
+#ifdef NM_STAMPS
+int nm_read_stamps(unsigned long long* out16, int reset) {   // measurement builds only
+  (void)hipDeviceSynchronize();
+  if (out16 && hipMemcpyFromSymbol(out16, HIP_SYMBOL(nm::g_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return fail("nm_read_stamps: copy failed");
+  unsigned long long z[16] = {0};
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(nm::g_stamps), z, sizeof z) != hipSuccess) return fail("nm_read_stamps: reset failed");
+  return 0;
+}
+#endif
 int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count) { NEED(env); return env->profiling(enable, sum_ms, count); }
 }

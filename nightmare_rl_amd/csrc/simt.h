@@ -76,6 +76,8 @@ NM_FN bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0;
 template <int CTRL> NM_FN int dpp(int x) { return __builtin_amdgcn_mov_dpp(x, CTRL, 0xF, 0xF, true); }
 template <int CTRL> NM_FN float dpp(float x) { return __int_as_float(dpp<CTRL>(__float_as_int(x))); }
 template <int CTRL> NM_FN double dpp(double x) { return __hiloint2double(dpp<CTRL>(__double2hiint(x)), dpp<CTRL>(__double2loint(x))); }
+// quad_perm inside every aligned group of 4 lanes: lane q of a quad takes the value of lane ((P >> 2q) & 3) of its quad
+template <int P, class T> NM_FN T quad(T x) { return dpp<P>(x); }
 // value of lane (lane ^ 1) / (lane ^ 2)
 template <class T> NM_FN T shfl_xor1(T x) { return dpp<NM_DPP_QUAD_XOR1>(x); }
 template <class T> NM_FN T shfl_xor2(T x) { return dpp<NM_DPP_QUAD_XOR2>(x); }
@@ -204,6 +206,7 @@ NM_FN V<int> opaque_lane() { return lane_id(); }
 template <class T> NM_FN T uniform(const V<T>& x) { return x.v[0]; }
 template <class T> NM_FN T uniform(T x) { return x; }
 template <class T> NM_FN V<T> shfl_xor(const V<T>& x, int m) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[i ^ m]; return r; }
+template <int P, class T> NM_FN V<T> quad(const V<T>& x) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[(i & ~3) | ((P >> (2 * (i & 3))) & 3)]; return r; }
 template <class T> NM_FN V<T> shfl_xor1(const V<T>& x) { return shfl_xor(x, 1); }
 template <class T> NM_FN V<T> shfl_xor2(const V<T>& x) { return shfl_xor(x, 2); }
 template <class T> NM_FN V<T> half_mirror(const V<T>& x) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = x.v[(i & ~7) | (7 - (i & 7))]; return r; }
