@@ -40,15 +40,16 @@ constexpr int kMaxRow = 4 * kMaxCon;
 constexpr int kJRow = 16;              // LDS row: Jb6 Jl3 leg | Jm3 leg1 (body1 side of a tibia-tibia contact) pad2
 enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
 
-// model + config constants, converted once to `real` by the host and kept in HBM/L2 (shared by all envs)
+// model + config constants, converted once to `real` by the host. The device kernel copies the struct (3 KB in fp32) into LDS
+// when a wave starts, so every M.x below is an LDS broadcast read, not a scalar load through a pointer.
 template <class real> struct Model {
-  const real* legc;     // [6][kLegN]
-  const real* basec;    // [kBaseN]
-  const real* colc;     // [7][kColN]
-  const real* hullv;    // [nhull][4] xyz0, body frame
+  const real* hullv;    // [nhull][4] xyz0, body frame (HBM/L2: 27 KB)
   const int* hullnbr;   // [nhull][maxnbr] local vertex ids, -1 terminated
-  const real* footc;    // [6][4] foot site pos (tibia frame) + radius
-  const real* qpos0;    // [kNQ]
+  real legc[kNLEG * kLegN];    // the small tables travel inside the struct: the kernel keeps one copy per wave in LDS
+  real basec[kBaseN];
+  real colc[kNCOL * kColN];
+  real footc[kNLEG * 4];       // foot site pos (tibia frame) + radius
+  real qpos0[kNQ];
   int maxnbr;
   real total_mass;
   real h, kv, ctrl_max, grav, mu;
@@ -119,6 +120,10 @@ template <class real> struct Sh {
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
   int nfallback;
+  real ecmd[4], eepsum[8];        // env buffers fetched at load time for the epilogue: commands, episode sums
+  int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
+  unsigned ectr;                  // command RNG counter
+  int cstart[8], ccnt[8];         // contacts of colliding mesh g (0 = base, 1..6 = tibias): first index and count (floor contacts)
   int hcache[8];                  // support vertex of each colliding mesh found last time (warm start of the hull search)
 };
 
@@ -275,7 +280,7 @@ NM_FN void nm_stamp(int k) {   // k = -1 starts the clock, k = 10 is the last st
   if (threadIdx.x == 0) {
     if (k < 0) for (int i = 0; i < 16; i++) acc[i] = 0;
     else acc[k] += n - tl;
-    if (k == 10) for (int i = 0; i <= 10; i++) atomicAdd(&g_stamps[i], acc[i]);
+    if (k == 10) for (int i = 0; i < 16; i++) atomicAdd(&g_stamps[i], acc[i]);
     tl = n;
   }
 }
@@ -950,6 +955,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
   }
   int ncon = 0;
+  stsv(sh.ccnt, sel(lane < 8, lane, V<int>(0)), V<int>(0), lane < 8);
 #pragma unroll
   for (int g = 0; g < kNCOL; g++) {
     const real* R = sh.colR + 9 * g;
@@ -987,6 +993,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     sh.cleg[ncon] = g - 1;
     sh.cleg1[ncon] = -1;
     sh.cnrm[3 * ncon] = real(0); sh.cnrm[3 * ncon + 1] = real(0); sh.cnrm[3 * ncon + 2] = real(1);
+    const int cfirst = ncon;
     ncon++;
     // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
     const real tol = M.tol_planemesh * cc[3];
@@ -1009,6 +1016,8 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       sh.cnrm[3 * ncon] = real(0); sh.cnrm[3 * ncon + 1] = real(0); sh.cnrm[3 * ncon + 2] = real(1);
       ncon++;
     }
+    sh.cstart[g] = cfirst;
+    sh.ccnt[g] = ncon - cfirst;
   }
   sh.ncon = ncon;
   sh.anypair = 0;
@@ -1364,18 +1373,12 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   }
   nm_stamp(7);
   stsv(sh.efc_f, lane, f, lane < kMaxRow);
-  // ---- qfrc_constraint = J' f
-#pragma unroll
-  for (int j = 0; j < 6; j++) sh.qfc[j] = wsum<real>(Jb[j] * f);
-#pragma unroll
-  for (int l = 0; l < 6; l++)
-#pragma unroll
-    for (int k = 0; k < 3; k++) sh.qfc[6 + 3 * l + k] = wsum<real>(sel(L == l, Jl[k] * f, vr(real(0))) + sel(L1 == l, Jm[k] * f, vr(real(0))));
-  // ---- touch sensors (only the last forward pass is observable after mj_step)
+  // ---- qfrc_constraint = J' f and the touch sensors (only the last forward pass is observable after mj_step)
+  vr nf = vr(real(0));
+  VB hit = VB(false), hit1 = VB(false);
   if (last) {
-    vr nf = f + shfl_xor1(f);
+    nf = f + shfl_xor1(f);
     nf = nf + shfl_xor2(nf);  // contact normal force = sum of its 4 pyramid edge forces
-    VB head = act & ((lane & 3) == 0) & (nf > vr(real(0)));
     // foot site sphere (mjmodel.xml:49...): the ray from the contact point along -normal (sensor on body2) or +normal
     // (sensor on body1) must hit it (mju_rayGeom, sphere)
     auto foot_hit = [&](const V<int>& Lx, real sgn) {
@@ -1395,16 +1398,58 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       vr sq = vsqrt(vmax(det, vr(real(0))));
       return !(det < vr(real(1e-15))) & (((-b2 - sq) >= vr(real(0))) | ((-b2 + sq) >= vr(real(0))));
     };
-    VB hit = foot_hit(Lc, real(-1));
-    VB hit1 = VB(false);
+    hit = foot_hit(Lc, real(-1));
     if (anypair) hit1 = foot_hit(Lc1, real(1));
+  }
 #pragma unroll
-    for (int l = 0; l < 6; l++) {
-      VB on = (L == l) | (L1 == l);
-      sh.sens[l] = wsum<real>(sel(head & on, nf, vr(real(0))));          // tibia sites: 10 m spheres see every contact of the body
-      sh.sens[6 + l] = wsum<real>(sel(head & (((L == l) & hit) | ((L1 == l) & hit1)), nf, vr(real(0))));  // foot sites
+  for (int j = 0; j < 6; j++) sh.qfc[j] = wsum<real>(Jb[j] * f);
+  if (!anypair) {
+    // Floor-only env: the contacts of a leg are consecutive (stage B emits them mesh by mesh). Sum inside each contact's
+    // quad, park the per-contact sums in the row buffer, then lane (leg l, quantity q) adds up its leg's <= 4 contacts.
+    vr s3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vr x = Jl[k] * f;
+      x = x + shfl_xor1(x);
+      s3[k] = x + shfl_xor2(x);
     }
-    sh.sens[12] = wsum<real>(sel(head & (L < 0), nf, vr(real(0))));
+    const vr tn = sel(act & (nf > vr(real(0))), nf, vr(real(0))), tf = sel(hit, tn, vr(real(0)));
+    const VB lead = act & ((lane & 3) == 0);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) stsv(jrow, c * 8 + k, s3[k], lead);
+    if (last) { stsv(jrow, c * 8 + 3, tn, lead); stsv(jrow, c * 8 + 4, tf, lead); }
+    wave_sync();
+    const VB on = lane < 30;
+    const V<int> lg = sel(on, (lane * 13) >> 6, V<int>(0)), qq = lane - lg * 5;
+    const V<int> c0 = ldsv(sh.cstart, lg + 1), cn = ldsv(sh.ccnt, lg + 1);
+    vr acc = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      VB in = on & (cn > k);
+      acc = acc + sel(in, ldsv(jrow, sel(in, (c0 + k) * 8 + qq, V<int>(0))), vr(real(0)));
+    }
+    stsv(sh.qfc, 6 + lg * 3 + qq, acc, on & (qq < 3));
+    if (last) {
+      stsv(sh.sens, lg, acc, on & (qq == 3));          // tibia sites: 10 m spheres see every contact of the body
+      stsv(sh.sens, lg + 6, acc, on & (qq == 4));      // foot sites
+      sh.sens[12] = wsum<real>(sel(act & ((lane & 3) == 0) & (L < 0), tn, vr(real(0))));
+    }
+  } else {
+#pragma unroll
+    for (int l = 0; l < 6; l++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) sh.qfc[6 + 3 * l + k] = wsum<real>(sel(L == l, Jl[k] * f, vr(real(0))) + sel(L1 == l, Jm[k] * f, vr(real(0))));
+    if (last) {
+      VB head = act & ((lane & 3) == 0) & (nf > vr(real(0)));
+#pragma unroll
+      for (int l = 0; l < 6; l++) {
+        VB onl = (L == l) | (L1 == l);
+        sh.sens[l] = wsum<real>(sel(head & onl, nf, vr(real(0))));
+        sh.sens[6 + l] = wsum<real>(sel(head & (((L == l) & hit) | ((L1 == l) & hit1)), nf, vr(real(0))));
+      }
+      sh.sens[12] = wsum<real>(sel(head & (L < 0), nf, vr(real(0))));
+    }
   }
   wave_sync();
 }
@@ -1616,6 +1661,15 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   act = (real)af;
 #endif
   if (!A.physics_only) {
+    // what the epilogue needs from HBM is fetched now, under the physics, not when it is needed
+    stsv(sh.ecmd, lane, gldv(A.cmd, sel(lane < 3, lane, V<int>(0)) + env * 3), lane < 3);
+    stsv(sh.eepsum, lane, gldv(A.epsum, sel(lane < kNREW, lane, V<int>(0)) + env * kNREW), lane < kNREW);
+    {
+      const int64_t ep = A.eplen[env];
+      sh.eplen_lo = (int)(uint32_t)(ep & 0xffffffffll);
+      sh.eplen_hi = (int)(ep >> 32);
+      sh.ectr = A.rngctr[env];
+    }
     prev_act = gldv(A.act, l18c + env * kNU);
     prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
     dofpos_old = gldv(A.dofpos, l18c + env * kNU);
@@ -1681,9 +1735,10 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #endif
   }
   if (A.physics_only) return;
+  nm_stamp(11);
 
   // ---- E3 (env.py:212-232): frame transforms with the POST-integration quaternion, stale cvel/sensors
-  int64_t eplen = A.eplen[env] + 1;
+  int64_t eplen = (((int64_t)sh.eplen_hi << 32) | (int64_t)(uint32_t)sh.eplen_lo) + 1;
   real bq[4] = {sh.qpos[3], -sh.qpos[4], -sh.qpos[5], -sh.qpos[6]};  // mju_negQuat
   auto rot = [&](real* r, const real* v) {  // mju_rotVecQuat
     real tx = real(2) * (bq[2] * v[2] - bq[3] * v[1]), ty = real(2) * (bq[3] * v[0] - bq[1] * v[2]), tz = real(2) * (bq[1] * v[1] - bq[2] * v[0]);
@@ -1704,8 +1759,8 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     tib[l] = feet[l] == real(0) ? sh.sens[l] : real(0);  // env.py:232
   }
   // ---- E4 (env.py:235-236, 321-333): periodic command resample
-  real cmd[3] = {A.cmd[env * 3], A.cmd[env * 3 + 1], A.cmd[env * 3 + 2]};
-  uint32_t ctr = A.rngctr[env];
+  real cmd[3] = {sh.ecmd[0], sh.ecmd[1], sh.ecmd[2]};
+  uint32_t ctr = sh.ectr;
   auto resample = [&](int which) {
     real ux, uy;
     if (A.cmd_u) { ux = A.cmd_u[env * 4 + 2 * which]; uy = A.cmd_u[env * 4 + 2 * which + 1]; }
@@ -1720,7 +1775,16 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     real keep = vsqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1]) > real(0.02) ? real(1) : real(0);
     cmd[0] = cmd[0] * keep; cmd[1] = cmd[1] * keep;
   };
-  if (eplen % M.resample_every == 0) resample(0);
+  {
+    bool due;
+    if (eplen >= 0 && eplen < (1 << 22)) {   // episode lengths are a few thousand steps: float quotient + exact integer remainder
+      const int e32 = (int)eplen, R = M.resample_every;
+      const int q = (int)((float)e32 / (float)R);
+      const int r = e32 - q * R;             // q is off by at most one
+      due = r == 0 || r == R || r == -R;
+    } else due = eplen % M.resample_every == 0;
+    if (due) resample(0);
+  }
   // ---- E5 (env.py:239-258): termination
   bool time_out = (real)eplen > M.max_ep_len;
   bool reset = time_out;
@@ -1730,12 +1794,16 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     for (int l = 1; l < 6; l++) fm = vmax(fm, feet[l]);
     reset = reset | (fm > M.term_force);
     real nrm = vsqrt(pg[0] * pg[0] + pg[1] * pg[1] + pg[2] * pg[2]);
-    reset = reset | (vacos(-pg[2] / nrm) > real(1.0471975511965976));  // 60 deg
+    // angle(projected gravity, straight down) > 60 deg. The fp32 build compares cosines instead of calling acosf (equivalent
+    // except within an ulp of the threshold); the fp64 verification build keeps the reference's expression.
+    if (sizeof(real) == 8) reset = reset | (vacos(-pg[2] / nrm) > real(1.0471975511965976));
+    else reset = reset | (-pg[2] / nrm <= real(0.5));
   }
+  nm_stamp(12);
   // ---- E6 (env.py:274, 335-371): reset BEFORE rewards/obs: qpos0, zero velocity, new command, episode stats
   vr epsum[1];
   V<int> l8c = sel(lane < kNREW, lane, V<int>(0));
-  epsum[0] = gldv(A.epsum, l8c + env * kNREW);
+  epsum[0] = ldsv(sh.eepsum, l8c);
   if (reset) {
     gstv(A.qpos, lane + env * kNQ, gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
     gstv(A.qvel, lane + env * kNV, real(0), lane < kNV);
@@ -1750,6 +1818,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #endif
     epsum[0] = vr(real(0));
   }
+  nm_stamp(13);
   // ---- E7 (env.py:277-288, 399-497): rewards (alphabetical, termination last)
   real rt[kNREW];
   {
@@ -1777,6 +1846,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     for (int k = 0; k < kNREW; k++) add = wrlane(add, rt[k], k);
     gstv(A.epsum, lane + env * kNREW, epsum[0] + add, lane < kNREW);
   }
+  nm_stamp(14);
   // ---- E8 (env.py:291-311): observation (66), clipped, float32
   {
     real head[12] = {blv[0] * M.obs_lin, blv[1] * M.obs_lin, blv[2] * M.obs_lin, bav[0] * M.obs_ang, bav[1] * M.obs_ang, bav[2] * M.obs_ang,
@@ -1810,6 +1880,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     put(dofvel * M.obs_dofvel, lane + 30, l18);
     put(act, lane + 48, l18);
   }
+  nm_stamp(15);
   // ---- buffers the reference keeps between steps
   gstv(A.dofpos, lane + env * kNU, dofpos, l18);
   gstv(A.dofvel, lane + env * kNU, dofvel, l18);

@@ -28,9 +28,16 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 template <class real, int G>
 __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
   __shared__ nm::ShW<real, G> sh;
+  __shared__ nm::Model<real> Ms;   // this wave's copy of the model constants
   const int wave = blockIdx.x;
   if (wave * G >= A.N) return;
-  nm::wave_step<real, G>(sh, *Mp, A, wave);
+  {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(Mp);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&Ms);
+    for (int i = threadIdx.x; i < (int)(sizeof(nm::Model<real>) / 4); i += 64) dst[i] = src[i];
+    __syncthreads();
+  }
+  nm::wave_step<real, G>(sh, Ms, A, wave);
 }
 
 // reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
@@ -150,9 +157,7 @@ template <class real> struct Env : nm_env {
     memset(&M, 0, sizeof M);
     memset(&A, 0, sizeof A);
     T.fill_scalars(M, cfg);
-    if (upload(&M.legc, T.legc) || upload(&M.basec, T.basec) || upload(&M.colc, T.colc) || upload(&M.hullv, T.hullv) ||
-        upload(&M.hullnbr, T.hullnbr) || upload(&M.footc, T.footc) || upload(&M.qpos0, T.qpos0))
-      return 1;
+    if (upload(&M.hullv, T.hullv) || upload(&M.hullnbr, T.hullnbr)) return 1;
     A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
     size_t n_ = (size_t)N;
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||

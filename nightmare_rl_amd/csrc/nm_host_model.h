@@ -1,6 +1,7 @@
 // nm_host_model.h - host side: turn the generated model tables (model/nm_model_data.h, doubles) and the
 // env configuration (reference envs/nightmare_v3_config.py) into the flat `real` arrays nm::Model<real> points at.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -106,6 +107,8 @@ template <class real> struct Tables {
 
   // scalars of nm::Model (pointers are set by the caller: host pointers for the emulation, device pointers for HIP)
   void fill_scalars(nm::Model<real>& M, const EnvConfig& cfg) const {
+    std::copy(legc.begin(), legc.end(), M.legc); std::copy(basec.begin(), basec.end(), M.basec); std::copy(colc.begin(), colc.end(), M.colc);
+    std::copy(footc.begin(), footc.end(), M.footc); std::copy(qpos0.begin(), qpos0.end(), M.qpos0);
     M.maxnbr = NM_HULL_MAXNBR;
     M.total_mass = (real)total_mass;
     M.h = (real)NM_TIMESTEP; M.kv = (real)NM_KV; M.ctrl_max = (real)NM_CTRL_MAX; M.grav = (real)(-nm_gravity[2]); M.mu = (real)NM_FRICTION;

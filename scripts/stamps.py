@@ -15,9 +15,10 @@ K = 200
 for i in range(K): env.step(acts[i % 16])
 env._L.nm_read_stamps(out, 0)
 names = ["load", "check+normalise", "A smooth", "B floor collision", "B tibia pairs", "C rows+project (A matrix)", "C warm start+PGS",
-         "C noslip", "C J'f+sensors", "D integrate", "epilogue+store"]
+         "C noslip", "C J'f+sensors", "D integrate", "epilogue: buffers + lane-0 stores", "epilogue: state stores", "epilogue: E3-E5 frames/termination", "epilogue: E6 reset",
+         "epilogue: E7 rewards", "epilogue: E8 observation"]
 waves = (N + 1) // 2
-tot = sum(out[:11])
+tot = sum(out[:16])
 for k, n in enumerate(names):
     print(f"{n:28s} {out[k] / K / waves:10.0f} ticks/wave/step  {100.0 * out[k] / tot:5.1f} %")
 print(f"{'total':28s} {tot / K / waves:10.0f} ticks/wave/step (s_memtime ticks)")

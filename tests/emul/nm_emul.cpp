@@ -48,8 +48,7 @@ template <class real> struct Emu : EmuBase {
     T.build();
     nmhost::EnvConfig cfg;
     T.fill_scalars(M, cfg);
-    M.legc = T.legc.data(); M.basec = T.basec.data(); M.colc = T.colc.data(); M.hullv = T.hullv.data();
-    M.hullnbr = T.hullnbr.data(); M.footc = T.footc.data(); M.qpos0 = T.qpos0.data();
+    M.hullv = T.hullv.data(); M.hullnbr = T.hullnbr.data();
     qpos.assign((size_t)N * 25, 0); qvel.assign((size_t)N * 24, 0); qwarm.assign((size_t)N * 24, 0);
     dofpos.assign((size_t)N * 18, 0); dofvel.assign((size_t)N * 18, 0); act.assign((size_t)N * 18, 0);
     cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * 8, 0); ep.assign(N, 0); ctr.assign(N, 0); hcache.assign((size_t)N * 8, 0);
