@@ -119,7 +119,7 @@ template <class real> struct Sh {
   real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
-  int nfallback;
+  int nfallback, nhop;
   real ecmd[4], eepsum[8];        // env buffers fetched at load time for the epilogue: commands, episode sums
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
   unsigned ectr;                  // command RNG counter
@@ -908,17 +908,23 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
 // =========================================================================================  stage B
 // Floor (z = 0) against the convex hulls of base_link and the six tibias.
 // Support vertex of hull g along ld (mesh frame) by exhaustive scan, lowest index wins ties (the reference rule).
+constexpr int kHullIters = 5;   // ceil(largest hull / 64): 284 vertices (host asserts it)
 template <class real> NM_FN int support_exhaustive(const Model<real>& M, const real* ld, int nvert, int vadr) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   vr best = vr(real(-1e30));
   V<int> ibest = lane;
-  for (int it = 0; it * NM_WAVE < nvert; it++) {
+  vr v[kHullIters][3];
+#pragma unroll
+  for (int it = 0; it < kHullIters; it++) {   // all gathers in flight at once: one L2 round trip, not five
+    V<int> vi = lane + it * NM_WAVE;
+    gld3(M.hullv, (sel(vi < nvert, vi, V<int>(0)) + vadr) * 4, v[it]);
+  }
+#pragma unroll
+  for (int it = 0; it < kHullIters; it++) {
     V<int> vi = lane + it * NM_WAVE;
     VB ok = vi < nvert;
-    vr v[3];
-    gld3(M.hullv, (sel(ok, vi, V<int>(0)) + vadr) * 4, v);
-    vr val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
+    vr val = ld[0] * v[it][0] + ld[1] * v[it][1] + ld[2] * v[it][2];
     VB take = ok & (val > best);
     best = sel(take, val, best);
     ibest = sel(take, vi, ibest);
@@ -927,6 +933,8 @@ template <class real> NM_FN int support_exhaustive(const Model<real>& M, const r
   wargmax(best, ibest, &sv, &si);
   return si;
 }
+template <class real> NM_FN real hull_tie_tol() { return sizeof(real) == 8 ? real(1e-13) : real(4e-7); }  // metres; >> rounding of ld.v
+constexpr int kMaxHop = 3;
 
 // Floor (z = 0) against the convex hulls of base_link and the six tibias. Like mjc_support, the search for the
 // support vertex is warm-started: lanes 0..maxnbr-1 evaluate the hull neighbours of last time's support vertex and lane
@@ -954,71 +962,99 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     const int vadr = (int)M.colc[kColN * g + 6];
     gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
   }
-  int ncon = 0;
-  stsv(sh.ccnt, sel(lane < 8, lane, V<int>(0)), V<int>(0), lane < 8);
+  // The seven meshes go through the stage together, phase by phase, so that their (independent) dependency chains overlap:
+  // P1 frame scalars + bounding-sphere prefilter, P2 support values and the occasional hill climb, P3 contact emission with
+  // contact slots from a running count (the order - mesh by mesh, support vertex first, then neighbours in graph order - is
+  // what the Gauss-Seidel sweeps downstream depend on).
+  real pz[kNCOL], ldv[kNCOL][3], sv[kNCOL];
+  bool near[kNCOL];
+  vr val[kNCOL];
+#pragma unroll
+  for (int g = 0; g < kNCOL; g++) {
+    const real* R = sh.colR + 9 * g;
+    const real* cc = M.colc + kColN * g;
+    pz[g] = sh.colp[3 * g + 2] + bz;
+    const real cz = R[6] * cc[0] + R[7] * cc[1] + R[8] * cc[2] + pz[g];
+    near[g] = !(cz - cc[3] > real(0));                    // bounding-sphere prefilter
+    ldv[g][0] = -R[6]; ldv[g][1] = -R[7]; ldv[g][2] = -R[8];  // -normal in the mesh frame
+    val[g] = ldv[g][0] * vv[g][0] + ldv[g][1] * vv[g][1] + ldv[g][2] * vv[g][2];
+    sv[g] = rdlane(val[g], kSelfLane);
+  }
+#pragma unroll
+  for (int g = 0; g < kNCOL; g++) {
+    const real tol = hull_tie_tol<real>();
+    if (near[g] && wany(nbl & (nb[g] >= 0) & (val[g] >= vr(sv[g] - tol)))) {
+      // Hill climbing on the hull graph (what mjc_support's warm start does): while a neighbour is clearly higher, move to
+      // the highest one. A vertex that beats all its neighbours by a margin is the support vertex of a convex hull. Near
+      // ties (and walks longer than kMaxHop) go to the exhaustive scan, whose lowest-index rule is the reference behaviour.
+      const int nvert = (int)M.colc[kColN * g + 5], vadr = (int)M.colc[kColN * g + 6];
+      const real* ld = ldv[g];
+      int si = cur[g];
+      bool full = false;
+      for (int hop = 0;; hop++) {
+        const VB nbv = nbl & (nb[g] >= 0);
+        if (!wany(nbv & (val[g] >= vr(sv[g] - tol)))) break;
+        if (hop == kMaxHop || !wany(nbv & (val[g] > vr(sv[g] + tol)))) { full = true; break; }
+        real bv;
+        wargmax(sel(nbv, val[g], vr(real(-1e30))), nb[g], &bv, &si);
+        nb[g] = sel(lane == kSelfLane, V<int>(si), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + si) * M.maxnbr), V<int>(-1)));
+        gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
+        val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
+        sv[g] = rdlane(val[g], kSelfLane);
+        sh.nhop += 1;
+      }
+      if (full) {
+        si = support_exhaustive(M, ld, nvert, vadr);
+        sh.nfallback += 1;
+        nb[g] = sel(lane == kSelfLane, V<int>(si), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + si) * M.maxnbr), V<int>(-1)));
+        gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
+        val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
+        sv[g] = rdlane(val[g], kSelfLane);
+      }
+      if (si != cur[g]) sh.hcache[g] = si;
+    }
+  }
+  int total = 0;   // contacts found so far (not capped)
 #pragma unroll
   for (int g = 0; g < kNCOL; g++) {
     const real* R = sh.colR + 9 * g;
     const real* p = sh.colp + 3 * g;
-    const real* cc = M.colc + kColN * g;
-    const real pz = p[2] + bz;
-    // bounding-sphere prefilter
-    real cz = R[6] * cc[0] + R[7] * cc[1] + R[8] * cc[2] + pz;
-    if (cz - cc[3] > real(0)) continue;
-    const int nvert = (int)cc[5], vadr = (int)cc[6];
-    const real ld[3] = {-R[6], -R[7], -R[8]};  // -normal in the mesh frame
-    V<int> nbg = nb[g];
-    vr v[3] = {vv[g][0], vv[g][1], vv[g][2]};
-    vr val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
-    int si = cur[g];
-    real sv = rdlane(val, kSelfLane);
-    if (wany(nbl & (nbg >= 0) & (val >= vr(sv)))) {  // not (strictly) the maximiser any more: full search, then its neighbours
-      si = support_exhaustive(M, ld, nvert, vadr);
-      sh.hcache[g] = si;
-      sh.nfallback += 1;
-      nbg = sel(lane == kSelfLane, V<int>(si), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + si) * M.maxnbr), V<int>(-1)));
-      gld3(M.hullv, (vmax(nbg, V<int>(0)) + vadr) * 4, v);
-      val = ld[0] * v[0] + ld[1] * v[1] + ld[2] * v[2];
-      sv = rdlane(val, kSelfLane);
-    }
-    const real dist = pz - sv;
-    if (dist >= real(0)) continue;
-    if (ncon >= kMaxCon) { *dropped += 1; continue; }
+    const real dist = pz[g] - sv[g];
+    const bool hitg = near[g] && dist < real(0);
     vr pnt[3];
-    matvec3(pnt, R, v);
+    matvec3(pnt, R, vv[g]);
     pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
     const real first[3] = {rdlane(pnt[0], kSelfLane), rdlane(pnt[1], kSelfLane), rdlane(pnt[2], kSelfLane) - real(0.5) * dist};
-    sh.cpos[3 * ncon] = first[0]; sh.cpos[3 * ncon + 1] = first[1]; sh.cpos[3 * ncon + 2] = first[2];
-    sh.cdist[ncon] = dist;
-    sh.cleg[ncon] = g - 1;
-    sh.cleg1[ncon] = -1;
-    sh.cnrm[3 * ncon] = real(0); sh.cnrm[3 * ncon + 1] = real(0); sh.cnrm[3 * ncon + 2] = real(1);
-    const int cfirst = ncon;
-    ncon++;
     // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
-    const real tol = M.tol_planemesh * cc[3];
+    const real tol = M.tol_planemesh * M.colc[kColN * g + 3];
     vr dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
     vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
-    VB ok = nbl & (nbg >= 0) & (val > vr(pz)) & !(vsqrt(d2) < vr(tol));
-    uint64_t m = ballot(ok);
-    for (int extra = 0; extra < 3 && m; extra++) {
-      int e = __builtin_ctzll(m);
-      m &= m - 1;
-      if (ncon >= kMaxCon) { *dropped += 1; continue; }
-      VB me = lane == e;
-      vr cd = pnt[2] + bz;
-      stsv(sh.cpos, V<int>(3 * ncon), pnt[0], me);
-      stsv(sh.cpos, V<int>(3 * ncon + 1), pnt[1], me);
-      stsv(sh.cpos, V<int>(3 * ncon + 2), pnt[2] - real(0.5) * cd, me);
-      stsv(sh.cdist, V<int>(ncon), cd, me);
-      sh.cleg[ncon] = g - 1;
-      sh.cleg1[ncon] = -1;
-      sh.cnrm[3 * ncon] = real(0); sh.cnrm[3 * ncon + 1] = real(0); sh.cnrm[3 * ncon + 2] = real(1);
-      ncon++;
-    }
-    sh.cstart[g] = cfirst;
-    sh.ccnt[g] = ncon - cfirst;
+    const VB ok = nbl & (nb[g] >= 0) & (val[g] > vr(pz[g])) & !(vsqrt(d2) < vr(tol));
+    const uint64_t m = ballot(ok);
+    const int nextra = vmin(popc64(m), 3);
+    const V<int> rank = lane_rank(m);
+    const VB self = lane == kSelfLane;
+    const V<int> slot = sel(self, V<int>(total), rank + (total + 1));
+    const VB wr = VB(hitg) & (self | (ok & (rank < 3))) & (slot < kMaxCon);
+    const V<int> sl = sel(wr, slot, V<int>(0));
+    const vr cd = sel(self, vr(dist), pnt[2] + bz);
+    stsv(sh.cpos, sl * 3, pnt[0], wr);
+    stsv(sh.cpos, sl * 3 + 1, pnt[1], wr);
+    stsv(sh.cpos, sl * 3 + 2, pnt[2] - real(0.5) * cd, wr);
+    stsv(sh.cdist, sl, cd, wr);
+    stsv(sh.cleg, sl, g - 1, wr);
+    stsv(sh.cleg1, sl, -1, wr);
+    stsv(sh.cnrm, sl * 3, real(0), wr);
+    stsv(sh.cnrm, sl * 3 + 1, real(0), wr);
+    stsv(sh.cnrm, sl * 3 + 2, real(1), wr);
+    const int ng = hitg ? 1 + nextra : 0;
+    const int c0 = vmin(total, kMaxCon), c1 = vmin(total + ng, kMaxCon);
+    sh.cstart[g] = c0;
+    sh.ccnt[g] = c1 - c0;
+    total += ng;
   }
+  const int ncon = vmin(total, kMaxCon);
+  *dropped += total - ncon;
   sh.ncon = ncon;
   sh.anypair = 0;
   wave_sync();
@@ -1644,6 +1680,7 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   stsv(sh.warm, lane, gldv(A.qwarm, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
   sh.nwarn = 0;
   sh.nfallback = 0;
+  sh.nhop = 0;
   stsv(sh.hcache, lane, gldv(A.hullcache, sel(lane < 8, lane, V<int>(0)) + env * 8), lane < 8);
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
   V<float> a_in = gldv(A.actions, l18c + env * kNU);

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 #include "../model/nm_model_data.h"
@@ -84,6 +85,7 @@ template <class real> struct Tables {
       for (int j = 0; j < 3; j++) c[j] = (real)nm_col_center[g][j];
       c[3] = (real)nm_col_rbound[g];
       c[4] = (real)nm_body_invweight0[nm_col_body[g]][0];
+      if (nm_col_nvert[g] > nm::kHullIters * NM_WAVE) std::abort();  // support_exhaustive covers kHullIters x 64 vertices
       c[5] = (real)nm_col_nvert[g];
       c[6] = (real)nm_col_vadr[g];
       for (int j = 0; j < 3; j++) c[8 + j] = (real)nm_col_obb_center[g][j];

@@ -104,6 +104,9 @@ template <class T> NM_FN T wsum(T x) {
   return (rdlane(x, 0) + rdlane(x, 16)) + (rdlane(x, 32) + rdlane(x, 48));
 }
 NM_FN bool wany(bool c) { return __ballot(c) != 0ull; }
+// number of set bits of the wave-uniform mask m below this lane (v_mbcnt)
+NM_FN int lane_rank(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
+NM_FN int popc64(uint64_t m) { return __popcll(m); }
 NM_FN uint64_t ballot(bool c) { return __ballot(c); }
 // argmax with lowest-index tie break; returns uniform (value, index)
 template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
@@ -224,6 +227,8 @@ template <class T> NM_FN T wsum(V<T> x) {
   return (x.v[0] + x.v[16]) + (x.v[32] + x.v[48]);
 }
 NM_FN bool wany(const VB& c) { for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) return true; return false; }
+NM_FN V<int> lane_rank(uint64_t m) { V<int> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = __builtin_popcountll(m & ((1ull << i) - 1ull)); return r; }
+NM_FN int popc64(uint64_t m) { return __builtin_popcountll(m); }
 NM_FN uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) m |= 1ull << i; return m; }
 template <class T> NM_FN void wargmax(V<T> val, V<int> idx, T* best, int* ibest) {
   T bv = val.v[0]; int bi = idx.v[0];
