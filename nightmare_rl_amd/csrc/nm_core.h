@@ -44,7 +44,8 @@ enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R
 // when a wave starts, so every M.x below is an LDS broadcast read, not a scalar load through a pointer.
 template <class real> struct Model {
   const real* hullv;    // [nhull][4] xyz0, body frame (HBM/L2: 27 KB)
-  const int* hullnbr;   // [nhull][maxnbr] local vertex ids, -1 terminated
+  const real* hullnv;   // [nhull][maxnbr+1][4]: per vertex, its hull neighbours as (x, y, z, local id or -1) and, last, itself:
+                        // one coalesced gather gives a vertex's whole ring (HBM/L2: 0.95 MB)
   real legc[kNLEG * kLegN];    // the small tables travel inside the struct: the kernel keeps one copy per wave in LDS
   real basec[kBaseN];
   real colc[kNCOL * kColN];
@@ -120,6 +121,7 @@ template <class real> struct Sh {
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
   int nfallback, nhop;
+  real eact[kNU], epact[kNU], epdv[kNU];  // this step's clipped actions, last step's actions and joint velocities (epilogue inputs)
   real ecmd[4], eepsum[8];        // env buffers fetched at load time for the epilogue: commands, episode sums
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
   unsigned ectr;                  // command RNG counter
@@ -300,7 +302,7 @@ template <class real, int G> struct Grp {  // lane -> (env slot, leg) mapping of
   V<int> sub, leg, eo;
   VB gact, isleg, lead;
   NM_FN Grp() {
-    const V<int> lane = lane_id();
+    const V<int> lane = opaque_lane();   // recomputed per stage: cheaper than keeping the mapping live (spilled) across stages
     sub = lane & 7;
     leg = vmin(sub, V<int>(5));
     V<int> g = lane >> 3;
@@ -942,12 +944,20 @@ constexpr int kMaxHop = 3;
 // does the mesh fall back to the exhaustive scan - so the result is always the exhaustive one (lowest index on ties).
 // The same neighbour data then yields the <= 3 extra plane-mesh contacts.
 constexpr int kSelfLane = 63;
+// lanes 0..maxnbr-1: the hull neighbours of global vertex gv (id -1 = none), lane 63: the vertex itself (local id `self`)
+template <class real> NM_FN void hull_ring(const Model<real>& M, int gv, int self, V<int>& nbg, V<real>* v) {
+  const V<int> lane = lane_id();
+  const VB nbl = lane < M.maxnbr;
+  V<real> o[4];
+  gld4(M.hullnv, (sel(nbl, lane, V<int>(M.maxnbr)) + gv * (M.maxnbr + 1)) * 4, o);
+  v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
+  nbg = sel(lane == kSelfLane, V<int>(self), sel(nbl, to_int(o[3]), V<int>(-1)));
+}
 template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped, bool pairs = true) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const real bz = sh.qpos[2];
   const VB nbl = lane < M.maxnbr;
-  const V<int> nbslot = sel(nbl, lane, V<int>(0));
   V<int> nb[kNCOL];
   vr vv[kNCOL][3];
   int cur[kNCOL];
@@ -955,12 +965,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
   for (int g = 0; g < kNCOL; g++) {
     const int vadr = (int)M.colc[kColN * g + 6];
     cur[g] = uniform(sh.hcache[g]);
-    nb[g] = sel(lane == kSelfLane, V<int>(cur[g]), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + cur[g]) * M.maxnbr), V<int>(-1)));
-  }
-#pragma unroll
-  for (int g = 0; g < kNCOL; g++) {
-    const int vadr = (int)M.colc[kColN * g + 6];
-    gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
+    hull_ring(M, vadr + cur[g], cur[g], nb[g], vv[g]);
   }
   // The seven meshes go through the stage together, phase by phase, so that their (independent) dependency chains overlap:
   // P1 frame scalars + bounding-sphere prefilter, P2 support values and the occasional hill climb, P3 contact emission with
@@ -997,8 +1002,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
         if (hop == kMaxHop || !wany(nbv & (val[g] > vr(sv[g] + tol)))) { full = true; break; }
         real bv;
         wargmax(sel(nbv, val[g], vr(real(-1e30))), nb[g], &bv, &si);
-        nb[g] = sel(lane == kSelfLane, V<int>(si), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + si) * M.maxnbr), V<int>(-1)));
-        gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
+        hull_ring(M, vadr + si, si, nb[g], vv[g]);
         val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
         sv[g] = rdlane(val[g], kSelfLane);
         sh.nhop += 1;
@@ -1006,8 +1010,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       if (full) {
         si = support_exhaustive(M, ld, nvert, vadr);
         sh.nfallback += 1;
-        nb[g] = sel(lane == kSelfLane, V<int>(si), sel(nbl, gldv(M.hullnbr, nbslot + (vadr + si) * M.maxnbr), V<int>(-1)));
-        gld3(M.hullv, (vmax(nb[g], V<int>(0)) + vadr) * 4, vv[g]);
+        hull_ring(M, vadr + si, si, nb[g], vv[g]);
         val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
         sv[g] = rdlane(val[g], kSelfLane);
       }
@@ -1635,7 +1638,7 @@ template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) 
 
 // mj_step(model, data, 1) for the G envs of the wave
 template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<real>& M, bool last, int* dropped, int ablate) {
-  const V<int> lane = lane_id();
+  const V<int> lane = opaque_lane();
   for (int e = 0; e < G; e++) {
     Sh<real>& sh = w.e[e];
     {  // mj_checkPos / mj_checkVel
@@ -1666,12 +1669,11 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
 }
 
 // =========================================================================================  env step
-template <class real> struct EnvRegs { V<real> act, prev_act, prev_dofvel, defp; };  // per-env values carried across the physics
 
 // load one env's state into its LDS image, action -> servo command (E1)
-template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env, EnvRegs<real>& rg) {
+template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env) {
   typedef V<real> vr;
-  const V<int> lane = lane_id();
+  const V<int> lane = opaque_lane();   // index math stays local to this function (not kept live across the physics)
   const VB l18 = lane < kNU;
   const V<int> l18c = sel(l18, lane, V<int>(0));
   // ---- load state
@@ -1714,19 +1716,25 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   } else {  // dynamics-only mode (BASELINE config 2): same PD law on the current joint angles, no env buffers
     stsv(sh.ctrl, lane, ((act - defp) - ldsv(sh.qpos, l18c + 7)) * M.p_gain, l18);
   }
-  rg.act = act; rg.prev_act = prev_act; rg.prev_dofvel = prev_dofvel; rg.defp = defp;
+  // carried to the epilogue through LDS, not in registers: nothing stays live across the physics
+  stsv(sh.eact, lane, act, l18); stsv(sh.epact, lane, prev_act, l18); stsv(sh.epdv, lane, prev_dofvel, l18);
   wave_sync();
 }
 
 // store one env's state, run the env epilogue (E3-E8). `live` = the slot holds a real env (last wave may be padded)
-template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env, const EnvRegs<real>& rg,
+template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env,
                                             int dropped, bool live) {
   typedef V<real> vr;
   if (!live) return;
-  const V<int> lane = lane_id();
+  const V<int> lane = opaque_lane();
   const VB l18 = lane < kNU;
   const V<int> l18c = sel(l18, lane, V<int>(0));
-  const vr act = rg.act, prev_act = rg.prev_act, prev_dofvel = rg.prev_dofvel, defp = rg.defp;
+  const vr act = ldsv(sh.eact, l18c), prev_act = ldsv(sh.epact, l18c), prev_dofvel = ldsv(sh.epdv, l18c);
+  vr defp;
+  {
+    V<int> m3 = lane % 3;
+    defp = sel(m3 == 1, vr(M.default_pos[1]), sel(m3 == 0, vr(M.default_pos[0]), vr(M.default_pos[2])));
+  }
   // ---- store physics state
   gstv(A.hullcache, lane + env * 8, ldsv(sh.hcache, sel(lane < 8, lane, V<int>(0))), lane < 8);
   gstv(A.qpos, lane + env * kNQ, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
@@ -1942,12 +1950,11 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 
 // one wavefront = G consecutive envs (E2, env.py:200: mj_step(model, data, decimation) between load and epilogue)
 template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave) {
-  EnvRegs<real> rg[G];
   nm_stamp(-1);
 #pragma unroll
   for (int e = 0; e < G; e++) {
     int env = wave * G + e;
-    env_load(w.e[e], M, A, env < A.N ? env : A.N - 1, rg[e]);
+    env_load(w.e[e], M, A, env < A.N ? env : A.N - 1);
   }
   nm_stamp(0);
   int dropped = 0;
@@ -1955,7 +1962,7 @@ template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<r
 #pragma unroll
   for (int e = 0; e < G; e++) {
     int env = wave * G + e;
-    env_finish(w.e[e], M, A, env, rg[e], e == 0 ? dropped : 0, env < A.N);
+    env_finish(w.e[e], M, A, env, e == 0 ? dropped : 0, env < A.N);
   }
   nm_stamp(10);
 }

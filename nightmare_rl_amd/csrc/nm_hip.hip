@@ -29,15 +29,17 @@ template <class real, int G>
 __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
   __shared__ nm::ShW<real, G> sh;
   __shared__ nm::Model<real> Ms;   // this wave's copy of the model constants
+  __shared__ nm::Args<real> As;    // ... and of the launch arguments: ~30 pointers would otherwise pin 60 SGPRs for the whole kernel
   const int wave = blockIdx.x;
   if (wave * G >= A.N) return;
+  As = A;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(Mp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&Ms);
     for (int i = threadIdx.x; i < (int)(sizeof(nm::Model<real>) / 4); i += 64) dst[i] = src[i];
     __syncthreads();
   }
-  nm::wave_step<real, G>(sh, Ms, A, wave);
+  nm::wave_step<real, G>(sh, Ms, As, wave);
 }
 
 // reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
@@ -157,7 +159,7 @@ template <class real> struct Env : nm_env {
     memset(&M, 0, sizeof M);
     memset(&A, 0, sizeof A);
     T.fill_scalars(M, cfg);
-    if (upload(&M.hullv, T.hullv) || upload(&M.hullnbr, T.hullnbr)) return 1;
+    if (upload(&M.hullv, T.hullv) || upload(&M.hullnv, T.hullnv)) return 1;
     A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
     size_t n_ = (size_t)N;
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||

@@ -50,7 +50,7 @@ inline void body_inertia6(const double* iquat, const double* diag, double* out) 
 
 template <class real> struct Tables {
   std::vector<real> legc, basec, colc, hullv, footc, qpos0;
-  std::vector<int> hullnbr;
+  std::vector<real> hullnv;
   double total_mass = 0;
 
   void build() {
@@ -95,9 +95,23 @@ template <class real> struct Tables {
     hullv.assign((size_t)NM_NHULLVERT * 4, real(0));
     for (int i = 0; i < NM_NHULLVERT; i++)
       for (int j = 0; j < 3; j++) hullv[4 * i + j] = (real)nm_hull_vert[i][j];
-    hullnbr.assign((size_t)NM_NHULLVERT * NM_HULL_MAXNBR, -1);
-    for (int i = 0; i < NM_NHULLVERT; i++)
-      for (int j = 0; j < NM_HULL_MAXNBR; j++) hullnbr[(size_t)i * NM_HULL_MAXNBR + j] = nm_hull_nbr[i][j];
+    {  // ring table: vertex -> (neighbour xyz, neighbour local id) x maxnbr, then the vertex itself
+      const int S = NM_HULL_MAXNBR + 1;
+      hullnv.assign((size_t)NM_NHULLVERT * S * 4, real(0));
+      for (int g = 0; g < nm::kNCOL; g++) {
+        const int vadr = nm_col_vadr[g], nv = nm_col_nvert[g];
+        for (int i = 0; i < nv; i++) {
+          real* row = &hullnv[(size_t)(vadr + i) * S * 4];
+          for (int j = 0; j < NM_HULL_MAXNBR; j++) {
+            const int n = nm_hull_nbr[vadr + i][j];
+            for (int k = 0; k < 3; k++) row[4 * j + k] = n >= 0 ? (real)nm_hull_vert[vadr + n][k] : real(0);
+            row[4 * j + 3] = (real)n;
+          }
+          for (int k = 0; k < 3; k++) row[4 * NM_HULL_MAXNBR + k] = (real)nm_hull_vert[vadr + i][k];
+          row[4 * NM_HULL_MAXNBR + 3] = (real)i;
+        }
+      }
+    }
     footc.assign(nm::kNLEG * 4, real(0));
     for (int l = 0; l < nm::kNLEG; l++) {
       for (int j = 0; j < 3; j++) footc[4 * l + j] = (real)nm_sens_pos[6 + l][j];

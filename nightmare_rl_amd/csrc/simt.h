@@ -138,6 +138,10 @@ template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; 
 template <class T> NM_FN T gldv(const T* p, int i) { return p[i]; }
 template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) p[i] = v; }
 // 3 consecutive values from a 4-element-aligned record: one vector load per lane
+NM_FN void gld4(const float* p, int i, float* o) { const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+NM_FN void gld4(const double* p, int i, double* o) { const double4 t = *reinterpret_cast<const double4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+NM_FN int to_int(float x) { return (int)x; }
+NM_FN int to_int(double x) { return (int)x; }
 NM_FN void gld3(const float* p, int i, float* o) { const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 NM_FN void gld3(const double* p, int i, double* o) { const double4 t = *reinterpret_cast<const double4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 NM_FN void wave_sync() { __syncthreads(); }
@@ -243,6 +247,8 @@ template <class T> NM_FN void stsv(T* a, const V<int>& i, T v, const VB& m) { fo
 template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p, i); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, const V<T>& v, const VB& m) { stsv(p, i, v, m); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, T v, const VB& m) { stsv(p, i, v, m); }
+template <class T> NM_FN void gld4(const T* p, const V<int>& i, V<T>* o) { for (int k = 0; k < NM_WAVE; k++) for (int c = 0; c < 4; c++) o[c].v[k] = p[i.v[k] + c]; }
+template <class T> NM_FN V<int> to_int(const V<T>& a) { V<int> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (int)a.v[i]; return r; }
 template <class T> NM_FN void gld3(const T* p, const V<int>& i, V<T>* o) { for (int k = 0; k < NM_WAVE; k++) for (int c = 0; c < 3; c++) o[c].v[k] = p[i.v[k] + c]; }
 template <class T> NM_FN void gld3(const T* p, int i, T* o) { o[0] = p[i]; o[1] = p[i + 1]; o[2] = p[i + 2]; }
 NM_FN void wave_sync() {}

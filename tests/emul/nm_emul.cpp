@@ -48,7 +48,7 @@ template <class real> struct Emu : EmuBase {
     T.build();
     nmhost::EnvConfig cfg;
     T.fill_scalars(M, cfg);
-    M.hullv = T.hullv.data(); M.hullnbr = T.hullnbr.data();
+    M.hullv = T.hullv.data(); M.hullnv = T.hullnv.data();
     qpos.assign((size_t)N * 25, 0); qvel.assign((size_t)N * 24, 0); qwarm.assign((size_t)N * 24, 0);
     dofpos.assign((size_t)N * 18, 0); dofvel.assign((size_t)N * 18, 0); act.assign((size_t)N * 18, 0);
     cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * 8, 0); ep.assign(N, 0); ctr.assign(N, 0); hcache.assign((size_t)N * 8, 0);
