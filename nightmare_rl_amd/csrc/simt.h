@@ -144,7 +144,14 @@ NM_FN int to_int(float x) { return (int)x; }
 NM_FN int to_int(double x) { return (int)x; }
 NM_FN void gld3(const float* p, int i, float* o) { const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 NM_FN void gld3(const double* p, int i, double* o) { const double4 t = *reinterpret_cast<const double4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
-NM_FN void wave_sync() { __syncthreads(); }
+// Orders this wave's LDS traffic: lanes exchange data through LDS only inside their own wavefront, whose DS instructions the
+// hardware executes in issue order, so all that is needed is that the compiler keeps the program order (no s_barrier, and no
+// draining of outstanding global loads/stores as __syncthreads() would do).
+NM_FN void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 // keep the scheduler from hoisting a later phase's loads across this point (they would sit in VGPRs and spill)
 NM_FN void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 }  // namespace simt
