@@ -371,17 +371,17 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
       vr q = LDL(qpos, leg * 3 + (7 + k)), qd = LDL(qvel, leg * 3 + (6 + k));
       vr pos[3], t3[3], aw[3], R[9];
       {
-        vr bpos[3] = {gldv(M.legc, cb), gldv(M.legc, cb + 1), gldv(M.legc, cb + 2)};
+        vr bpos[3] = {ldsv(M.legc, cb), ldsv(M.legc, cb + 1), ldsv(M.legc, cb + 2)};
         matvec3(t3, Rp, bpos);
         pos[0] = pp[0] + t3[0]; pos[1] = pp[1] + t3[1]; pos[2] = pp[2] + t3[2];
       }
       {
-        vr ax[3] = {gldv(M.legc, cb + 12), gldv(M.legc, cb + 13), gldv(M.legc, cb + 14)};
+        vr ax[3] = {ldsv(M.legc, cb + 12), ldsv(M.legc, cb + 13), ldsv(M.legc, cb + 14)};
         vr R0[9];
         {
           vr bR[9];
 #pragma unroll
-          for (int j = 0; j < 9; j++) bR[j] = gldv(M.legc, cb + 3 + j);
+          for (int j = 0; j < 9; j++) bR[j] = ldsv(M.legc, cb + 3 + j);
           matmul3(R0, Rp, bR);
         }
         matvec3(aw, R0, ax);
@@ -411,11 +411,11 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
       S[0] = aw[0]; S[1] = aw[1]; S[2] = aw[2];
       cross3(S + 3, pos, aw);  // motion vector about the base origin: [a; r x a]
       {
-        vr ipos[3] = {gldv(M.legc, cb + 15), gldv(M.legc, cb + 16), gldv(M.legc, cb + 17)};
+        vr ipos[3] = {ldsv(M.legc, cb + 15), ldsv(M.legc, cb + 16), ldsv(M.legc, cb + 17)};
         vr Ib[6];
 #pragma unroll
-        for (int j = 0; j < 6; j++) Ib[j] = gldv(M.legc, cb + 18 + j);
-        vr mass = gldv(M.legc, cb + 24);
+        for (int j = 0; j < 6; j++) Ib[j] = ldsv(M.legc, cb + 18 + j);
+        vr mass = ldsv(M.legc, cb + 24);
         vr d[3];
         matvec3(t3, R, ipos);
         d[0] = pos[0] + t3[0]; d[1] = pos[1] + t3[1]; d[2] = pos[2] + t3[2];
@@ -850,7 +850,7 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
 #pragma unroll
     for (int j = 0; j < 9; j++) R[j] = ldsv(sh.colR, gg[w] * 9 + j);
 #pragma unroll
-    for (int j = 0; j < 3; j++) oc[j] = gldv(M.colc, gg[w] * kColN + (8 + j));
+    for (int j = 0; j < 3; j++) oc[j] = ldsv(M.colc, gg[w] * kColN + (8 + j));
     matvec3(c, R, oc);
 #pragma unroll
     for (int j = 0; j < 3; j++) { c[j] = c[j] + ldsv(sh.colp, gg[w] * 3 + j); if (w == 0) c1[j] = c[j]; else c2[j] = c[j]; }
@@ -868,8 +868,8 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
     vr ext = vr(real(0));
 #pragma unroll
     for (int a = 0; a < 3; a++) {
-      vr ax[3] = {gldv(M.colc, gg[w] * kColN + (11 + 3 * a)), gldv(M.colc, gg[w] * kColN + (12 + 3 * a)), gldv(M.colc, gg[w] * kColN + (13 + 3 * a))};
-      ext += gldv(M.colc, gg[w] * kColN + (20 + a)) * vabs(ax[0] * ul[0] + ax[1] * ul[1] + ax[2] * ul[2]);
+      vr ax[3] = {ldsv(M.colc, gg[w] * kColN + (11 + 3 * a)), ldsv(M.colc, gg[w] * kColN + (12 + 3 * a)), ldsv(M.colc, gg[w] * kColN + (13 + 3 * a))};
+      ext += ldsv(M.colc, gg[w] * kColN + (20 + a)) * vabs(ax[0] * ul[0] + ax[1] * ul[1] + ax[2] * ul[2]);
     }
     e[w] = ext;
   }
@@ -1193,8 +1193,8 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     imp = sel(x >= vr(real(1)), vr(M.si_dmax), imp);
     imp = sel(x <= vr(real(0)), vr(M.si_d0), imp);
   }
-  vr invw = gldv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
-  if (anypair) invw = invw + sel(onleg1, gldv(M.colc, (Lc1 + 1) * kColN + 4), vr(real(0)));
+  vr invw = ldsv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
+  if (anypair) invw = invw + sel(onleg1, ldsv(M.colc, (Lc1 + 1) * kColN + 4), vr(real(0)));
   vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
   vr Dd = vr(real(1)) / Rr;
   // sparse dots with the wave-uniform vectors qvel, qacc_smooth, qacc_warmstart
@@ -1423,8 +1423,8 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     auto foot_hit = [&](const V<int>& Lx, real sgn) {
       vr ft[3], fr, s[3], Rt[9];
 #pragma unroll
-      for (int j = 0; j < 3; j++) s[j] = gldv(M.footc, Lx * 4 + j);
-      fr = gldv(M.footc, Lx * 4 + 3);
+      for (int j = 0; j < 3; j++) s[j] = ldsv(M.footc, Lx * 4 + j);
+      fr = ldsv(M.footc, Lx * 4 + 3);
 #pragma unroll
       for (int j = 0; j < 9; j++) Rt[j] = ldsv(sh.colR, (Lx + 1) * 9 + j);
       matvec3(ft, Rt, s);
@@ -1613,7 +1613,7 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
       Sh<real>& sh = w.e[e];
       const V<int> lane = lane_id();
       sh.nwarn += 1;
-      vr q0 = gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0)));
+      vr q0 = ldsv(M.qpos0, sel(lane < kNQ, lane, V<int>(0)));
       real vz = -M.grav * M.h;
       q0 = sel(lane == 2, q0 + vz * M.h, q0);
       stsv(sh.qpos, lane, q0, lane < kNQ);
@@ -1629,7 +1629,7 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
 
 template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) {  // mj_resetData
   const V<int> lane = lane_id();
-  stsv(sh.qpos, lane, gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
+  stsv(sh.qpos, lane, ldsv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
   stsv(sh.qvel, lane, real(0), lane < kNV);
   stsv(sh.warm, lane, real(0), lane < kNV);
   stsv(sh.ctrl, lane, real(0), lane < kNU);
@@ -1704,10 +1704,10 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
     stsv(sh.ecmd, lane, gldv(A.cmd, sel(lane < 3, lane, V<int>(0)) + env * 3), lane < 3);
     stsv(sh.eepsum, lane, gldv(A.epsum, sel(lane < kNREW, lane, V<int>(0)) + env * kNREW), lane < kNREW);
     {
-      const int64_t ep = A.eplen[env];
+      const int64_t ep = gld1(A.eplen, env);
       sh.eplen_lo = (int)(uint32_t)(ep & 0xffffffffll);
       sh.eplen_hi = (int)(ep >> 32);
-      sh.ectr = A.rngctr[env];
+      sh.ectr = gld1(A.rngctr, env);
     }
     prev_act = gldv(A.act, l18c + env * kNU);
     prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
@@ -1808,7 +1808,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
   uint32_t ctr = sh.ectr;
   auto resample = [&](int which) {
     real ux, uy;
-    if (A.cmd_u) { ux = A.cmd_u[env * 4 + 2 * which]; uy = A.cmd_u[env * 4 + 2 * which + 1]; }
+    if (A.cmd_u) { ux = gld1(A.cmd_u, env * 4 + 2 * which); uy = gld1(A.cmd_u, env * 4 + 2 * which + 1); }
     else {
       ux = (real)rand_u24_bits(A.seed, (uint64_t)(A.env_offset + env), ctr) * real(1.0 / 16777216.0);
       uy = (real)rand_u24_bits(A.seed, (uint64_t)(A.env_offset + env), ctr + 1) * real(1.0 / 16777216.0);
@@ -1850,7 +1850,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
   V<int> l8c = sel(lane < kNREW, lane, V<int>(0));
   epsum[0] = ldsv(sh.eepsum, l8c);
   if (reset) {
-    gstv(A.qpos, lane + env * kNQ, gldv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
+    gstv(A.qpos, lane + env * kNQ, ldsv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
     gstv(A.qvel, lane + env * kNV, real(0), lane < kNV);
     resample(1);
     eplen = 0;
@@ -1903,9 +1903,9 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
       vr x = x0;
       if (A.noise_vec) {  // env.py:304-305: + (2 U[0,1) - 1) * noise_scale_vec before the clip
         auto nz = [&](int k) {
-          real u = A.noise_u ? A.noise_u[(size_t)env * kNOBS + k]
+          real u = A.noise_u ? gld1(A.noise_u, (size_t)env * kNOBS + k)
                              : (real)rand_u24_bits(A.seed + kNoiseKey, (uint64_t)(A.env_offset + env), (uint32_t)(A.noise_step * kNOBS + k)) * real(1.0 / 16777216.0);
-          return (real(2) * u - real(1)) * A.noise_vec[k];
+          return (real(2) * u - real(1)) * gld1(A.noise_vec, k);
         };
 #ifdef NM_EMUL
         for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) x.v[i] = x.v[i] + nz(idx.v[i]);
@@ -1917,7 +1917,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #ifdef NM_EMUL
       for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) A.obs[(size_t)env * kNOBS + idx.v[i]] = (float)cx.v[i];
 #else
-      if (m) A.obs[(size_t)env * kNOBS + idx] = (float)cx;
+      if (m) gst1(A.obs, (size_t)env * kNOBS + idx, (float)cx);
 #endif
     };
     put(o, lane, lane < 12);
@@ -1940,11 +1940,11 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
   const bool lane0 = threadIdx.x == 0;
 #endif
   if (lane0) {
-    A.eplen[env] = eplen;
-    A.rngctr[env] = ctr;
-    A.rew[env] = (float)rew;
-    A.done[env] = reset ? 1 : 0;
-    A.timeout_now[env] = time_out ? 1.0f : 0.0f;
+    gst1(A.eplen, env, eplen);
+    gst1(A.rngctr, env, ctr);
+    gst1(A.rew, env, (float)rew);
+    gst1(A.done, env, (int64_t)(reset ? 1 : 0));
+    gst1(A.timeout_now, env, time_out ? 1.0f : 0.0f);
   }
 }
 

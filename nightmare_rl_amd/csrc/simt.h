@@ -135,15 +135,21 @@ template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
 }
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; }
-template <class T> NM_FN T gldv(const T* p, int i) { return p[i]; }
-template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) p[i] = v; }
-// 3 consecutive values from a 4-element-aligned record: one vector load per lane
-NM_FN void gld4(const float* p, int i, float* o) { const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
-NM_FN void gld4(const double* p, int i, double* o) { const double4 t = *reinterpret_cast<const double4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+// Global-memory accessors. The pointers reach the kernel through an LDS copy of the launch arguments / model struct, so
+// the compiler no longer knows their address space: the casts keep these global_load / global_store instead of flat_*.
+#define NM_GLOBAL(T) __attribute__((address_space(1))) T
+typedef float nm_f4 __attribute__((ext_vector_type(4)));
+typedef double nm_d4 __attribute__((ext_vector_type(4)));
+template <class T> NM_FN T gldv(const T* p, int i) { return ((const NM_GLOBAL(T)*)p)[i]; }
+template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) ((NM_GLOBAL(T)*)p)[i] = v; }
+template <class T> NM_FN T gld1(const T* p, size_t i) { return ((const NM_GLOBAL(T)*)p)[i]; }   // wave-uniform or single-lane
+template <class T> NM_FN void gst1(T* p, size_t i, T v) { ((NM_GLOBAL(T)*)p)[i] = v; }
+NM_FN void gld3(const float* p, int i, float* o) { const nm_f4 t = *(const NM_GLOBAL(nm_f4)*)((const NM_GLOBAL(float)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
+NM_FN void gld3(const double* p, int i, double* o) { const nm_d4 t = *(const NM_GLOBAL(nm_d4)*)((const NM_GLOBAL(double)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
+NM_FN void gld4(const float* p, int i, float* o) { const nm_f4 t = *(const NM_GLOBAL(nm_f4)*)((const NM_GLOBAL(float)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
+NM_FN void gld4(const double* p, int i, double* o) { const nm_d4 t = *(const NM_GLOBAL(nm_d4)*)((const NM_GLOBAL(double)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
 NM_FN int to_int(float x) { return (int)x; }
 NM_FN int to_int(double x) { return (int)x; }
-NM_FN void gld3(const float* p, int i, float* o) { const float4 t = *reinterpret_cast<const float4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
-NM_FN void gld3(const double* p, int i, double* o) { const double4 t = *reinterpret_cast<const double4*>(p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 // Orders this wave's LDS traffic: lanes exchange data through LDS only inside their own wavefront, whose DS instructions the
 // hardware executes in issue order, so all that is needed is that the compiler keeps the program order (no s_barrier, and no
 // draining of outstanding global loads/stores as __syncthreads() would do).
@@ -251,6 +257,8 @@ template <class T> NM_FN V<T> ldsv(const T* a, const V<int>& i) { V<T> r; for (i
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, const V<int>& i, const V<T>& v, const VB& m) { for (int k = 0; k < NM_WAVE; k++) if (m.v[k]) a[i.v[k]] = v.v[k]; }
 template <class T> NM_FN void stsv(T* a, const V<int>& i, T v, const VB& m) { for (int k = 0; k < NM_WAVE; k++) if (m.v[k]) a[i.v[k]] = v; }
+template <class T> NM_FN T gld1(const T* p, size_t i) { return p[i]; }
+template <class T> NM_FN void gst1(T* p, size_t i, T v) { p[i] = v; }
 template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p, i); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, const V<T>& v, const VB& m) { stsv(p, i, v, m); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, T v, const VB& m) { stsv(p, i, v, m); }
