@@ -44,7 +44,10 @@ class PPO:
         t.actions_log_prob = self.actor_critic.get_actions_log_prob(t.actions).detach()
         t.action_mean = self.actor_critic.action_mean.detach()
         t.action_sigma = self.actor_critic.action_std.detach()
-        t.observations, t.critic_observations = obs, critic_obs
+        # The env hands out views of persistent device buffers that the next step() overwrites (rsl_rl's envs return fresh
+        # tensors): keep what the policy actually saw.
+        t.observations = obs.clone()
+        t.critic_observations = t.observations if critic_obs is obs else critic_obs.clone()
         return t.actions
 
     def process_env_step(self, rewards, dones, infos):
@@ -91,6 +94,7 @@ class PPO:
                         dist.all_reduce(kl_mean)
                         kl_mean /= _world()
                     kl_mean = float(kl_mean)   # the one host sync per mini-batch the schedule needs
+                    self.last_kl = kl_mean
                 if kl_mean > self.desired_kl * 2.0:
                     self.learning_rate = max(1e-5, self.learning_rate / 1.5)
                 elif 0.0 < kl_mean < self.desired_kl / 2.0:

@@ -86,6 +86,7 @@ class OnPolicyRunner:
                 step_rew = alg.storage.rewards.mean()
                 alg.compute_returns(critic_obs)
             mean_value_loss, mean_surrogate_loss = alg.update()
+            kl = getattr(alg, "last_kl", float("nan"))
             learn_time = time.time() - start
             if _world() > 1:
                 dist.all_reduce(fin)
@@ -99,7 +100,7 @@ class OnPolicyRunner:
             self.tot_timesteps += steps
             self.tot_time += collection_time + learn_time
             rec = dict(it=it, fps=steps / (collection_time + learn_time), collection_time=collection_time, learn_time=learn_time,
-                       value_loss=mean_value_loss, surrogate_loss=mean_surrogate_loss, mean_reward=mean_ret, mean_episode_length=mean_len, mean_step_reward=f[3],
+                       value_loss=mean_value_loss, surrogate_loss=mean_surrogate_loss, kl=kl, mean_reward=mean_ret, mean_episode_length=mean_len, mean_step_reward=f[3],
                        action_std=float(alg.actor_critic.std.detach().mean()), lr=alg.learning_rate, total_timesteps=self.tot_timesteps)
             if ep_stats is not None and "episode" in infos:
                 for k, v in zip(sorted(infos["episode"]), (ep_stats / max(ep_n, 1)).tolist()):

@@ -96,3 +96,42 @@ def test_ppo_learns_toy_task(tmp_path):
     pol = r2.get_inference_policy()
     x = torch.rand(8, 3)
     torch.testing.assert_close(pol(x), runner.alg.actor_critic.act_inference(x))
+
+
+class BufferReusingEnv(ToyEnv):
+    """Like the HIP env: observations are views of ONE persistent buffer that the next step() overwrites."""
+
+    def __init__(self, n):
+        super().__init__(n)
+        self.obs_buf = self.t.clone()
+
+    def get_observations(self):
+        self.obs_buf.copy_(self.t)
+        return self.obs_buf
+
+    def step(self, a):
+        self.t += 0.01                       # the observation changes every step
+        return super().step(a)
+
+
+def test_rollout_keeps_the_observation_the_policy_saw():
+    """Regression: with an env that reuses its observation buffer, the stored (obs, mu, sigma) must stay consistent, otherwise the
+    KL estimate of the adaptive learning-rate schedule is garbage and the rate collapses to its floor."""
+    torch.manual_seed(0)
+    cfg = class_to_dict(NightmareV3ConfigPPO())
+    cfg["runner"]["num_steps_per_env"] = 8
+    env = BufferReusingEnv(64)
+    runner = OnPolicyRunner(env, cfg, log_dir=None, device="cpu")
+    alg = runner.alg
+    obs = env.get_observations()
+    seen = []
+    with torch.inference_mode():
+        for _ in range(8):
+            seen.append(obs.clone())
+            a = alg.act(obs, obs)
+            obs, _, rew, done, infos = env.step(a)
+            alg.process_env_step(rew, done, infos)
+    stored = alg.storage.observations
+    torch.testing.assert_close(stored, torch.stack(seen))
+    alg.actor_critic.act(stored.flatten(0, 1))
+    torch.testing.assert_close(alg.actor_critic.action_mean, alg.storage.mu.flatten(0, 1))      # same weights -> same means: KL = 0
