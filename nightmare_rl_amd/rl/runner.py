@@ -91,8 +91,9 @@ class OnPolicyRunner:
             if _world() > 1:
                 dist.all_reduce(fin)
             if _world() > 1:
+                step_rew = step_rew.clone()     # made under inference_mode above
                 dist.all_reduce(step_rew)
-                step_rew /= _world()
+                step_rew = step_rew / _world()
             f = fin.tolist() + [float(step_rew)]   # the one host read of episode statistics per iteration
             if f[2] > 0:
                 mean_ret, mean_len = f[0] / f[2], f[1] / f[2]

@@ -67,3 +67,46 @@ def test_two_rank_sharded_rollout_equals_single_rank():
         assert abs(mean - full_ret.astype(np.float64).mean()) < 1e-9
         assert abs(std - full_ret.astype(np.float64).std(ddof=1)) < 1e-9
     assert np.abs(full_cmd).sum() > 0
+
+
+def _ppo_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from test_rl import ToyEnv
+    from nightmare_rl_amd.envs.helpers import class_to_dict
+    from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3ConfigPPO
+    from nightmare_rl_amd.rl import OnPolicyRunner
+    torch.manual_seed(100 + rank)                      # different shards, different initial weights before the broadcast
+    cfg = class_to_dict(NightmareV3ConfigPPO())
+    cfg["runner"]["num_steps_per_env"] = 16
+    runner = OnPolicyRunner(ToyEnv(64), cfg, log_dir=None, device="cpu")
+    runner.learn(3)
+    flat = torch.cat([p.detach().reshape(-1) for p in runner.alg.actor_critic.parameters()])
+    q.put((rank, flat.numpy(), runner.alg.learning_rate, runner.history[-1]["mean_step_reward"]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_ppo_keeps_replicas_identical():
+    """Config 5's N>1 path: weights broadcast from rank 0, one flat gradient all-reduce per mini-batch, global KL for the
+    adaptive learning rate, global advantage statistics -> the replicas stay bit-identical although every rank sees other envs."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ppo_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, w0, lr0, r0), (_, w1, lr1, r1) = res
+    assert np.isfinite(w0).all()
+    np.testing.assert_array_equal(w0, w1)
+    assert lr0 == lr1
+    assert r0 == r1                                      # the logged step reward is the all-reduced mean
