@@ -1155,9 +1155,25 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   for (int j = 0; j < 6; j++) Fb[j] = sel(act, Fb[j], vr(real(0)));
 #pragma unroll
   for (int k = 0; k < 3; k++) Fl[k] = sel(act, Fl[k], vr(real(0)));
+  // A = J M^-1 J' through the block factor: with u_i = Jb_i - W_l' Jl_i (l = row i's leg; the base part of the row after
+  // eliminating its leg), xb_j = S^-1 u_j (Schur solve) and t_j = M_l^-1 Jl_j,   A_ij = u_i . xb_j + [l_i == l_j] Jl_i . t_j.
+  // So a row publishes (u, Jl) and a lane keeps (xb, t): no 24-vector B per lane, no reads of the other legs' W blocks.
+  vr uF[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    uF[j] = Fb[j];
+#pragma unroll
+    for (int k = 0; k < 3; k++) uF[j] = uF[j] - ldsv(sh.W, Lc * 18 + (6 * k + j)) * Fl[k];
+  }
+  if (anypair) {
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+#pragma unroll
+      for (int k = 0; k < 3; k++) uF[j] = uF[j] - ldsv(sh.W, Lc1 * 18 + (6 * k + j)) * Fm[k];
+  }
   // publish the frame rows (rows 4c, 4c+1, 4c+2 of the buffer = n, t1, t2 of contact c) for the projection sweep
 #pragma unroll
-  for (int j = 0; j < 6; j++) stsv(jrow, lane * kJRow + j, Fb[j], lane < kMaxRow);
+  for (int j = 0; j < 6; j++) stsv(jrow, lane * kJRow + j, uF[j], lane < kMaxRow);
 #pragma unroll
   for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (6 + k), Fl[k], lane < kMaxRow);
   if (anypair) {
@@ -1174,6 +1190,9 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
 #pragma unroll
     for (int k = 0; k < 3; k++) Jm[k] = quad<0x00>(Fm[k]) + smu * quad<0xA5>(Fm[k]);
   }
+  vr u[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) u[j] = quad<0x00>(uF[j]) + smu * quad<0xA5>(uF[j]);
 
   // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
   vr imp;
@@ -1218,99 +1237,64 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr aref = -M.solref_B * vel - M.solref_K * imp * dist;
   vr bb = jas - aref;
 
-  // B = M^-1 J' for this row (block factor; W/Minv of the row's own leg gathered per lane)
-  vr B[24];
+  // this lane's side of the projection: t = M_l^-1 Jl (own leg), xb = S^-1 u
+  vr t[3], t1m[3] = {vr(real(0)), vr(real(0)), vr(real(0))}, xb[6];
   {
-    vr t[3], Mi[6];
+    vr Mi[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) Mi[j] = ldsv(sh.Minv, Lc * 6 + j);
     ldl3_solve(t, Mi, Jl);
-    vr t1m[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
-    vr xb[6];
-#pragma unroll
-    for (int j = 0; j < 6; j++) {
-      xb[j] = Jb[j];
-#pragma unroll
-      for (int k = 0; k < 3; k++) xb[j] = xb[j] - ldsv(sh.W, Lc * 18 + (6 * k + j)) * Jl[k];
-    }
     if (anypair) {
       vr Mi1[6];
 #pragma unroll
       for (int j = 0; j < 6; j++) Mi1[j] = ldsv(sh.Minv, Lc1 * 6 + j);
       ldl3_solve(t1m, Mi1, Jm);
-#pragma unroll
-      for (int j = 0; j < 6; j++)
-#pragma unroll
-        for (int k = 0; k < 3; k++) xb[j] = xb[j] - ldsv(sh.W, Lc1 * 18 + (6 * k + j)) * Jm[k];
     }
+#pragma unroll
+    for (int j = 0; j < 6; j++) xb[j] = u[j];
     ldl6_solve(sh.Lb, sh.Dbi, xb);
-#pragma unroll
-    for (int j = 0; j < 6; j++) B[j] = xb[j];
-#pragma unroll
-    for (int l = 0; l < 6; l++)
-#pragma unroll
-      for (int k = 0; k < 3; k++) {
-        vr x = sel(L == l, t[k], vr(real(0)));
-        if (anypair) x = x + sel(L1 == l, t1m[k], vr(real(0)));
-#pragma unroll
-        for (int j = 0; j < 6; j++) x = x - sh.W[l * 18 + 6 * k + j] * xb[j];
-        B[6 + 3 * l + k] = x;
-      }
   }
   wave_sync();
-  // A[i] (in lane j) = J_i . B_j  -> lane j holds row j of the symmetric A = J M^-1 J'. Per contact: the three frame rows
-  // are read once (wave-uniform LDS reads), dotted with this lane's B, and combined into the four pyramid rows
-  // (n +- mu t1, n +- mu t2). The leg block of B is re-selected only when the contact's leg changes (contacts come grouped
-  // by mesh), so the sweep has no per-row branches.
+  // A[i] (in lane j) -> lane j holds row j of the symmetric A = J M^-1 J'. Per contact: the three frame rows are read once
+  // (wave-uniform LDS reads), contracted with this lane's (xb, t), and combined into the four pyramid rows (n +- mu t1,
+  // n +- mu t2); no per-row branches.
   vr A[kMaxRow];
 #pragma unroll
   for (int i = 0; i < kMaxRow; i++) A[i] = vr(real(0));
-  {
-    vr Bs[3] = {vr(real(0)), vr(real(0)), vr(real(0))}, Bs1[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
-    int Lprev = -2, L1prev = -2;
-    auto pick = [&](vr* o, int l) {
-      switch (l) {
-        case 0: o[0] = B[6]; o[1] = B[7]; o[2] = B[8]; break;
-        case 1: o[0] = B[9]; o[1] = B[10]; o[2] = B[11]; break;
-        case 2: o[0] = B[12]; o[1] = B[13]; o[2] = B[14]; break;
-        case 3: o[0] = B[15]; o[1] = B[16]; o[2] = B[17]; break;
-        case 4: o[0] = B[18]; o[1] = B[19]; o[2] = B[20]; break;
-        case 5: o[0] = B[21]; o[1] = B[22]; o[2] = B[23]; break;
-        default: o[0] = vr(real(0)); o[1] = vr(real(0)); o[2] = vr(real(0)); break;
-      }
-    };
 #pragma unroll
-    for (int cc = 0; cc < kMaxCon; cc++) {
-      if (cc < ncon) {
-        const int Lcc = uniform(sh.cleg[cc]);
-        if (Lcc != Lprev) { pick(Bs, Lcc); Lprev = Lcc; }
+  for (int cc = 0; cc < kMaxCon; cc++) {
+    if (cc < ncon) {
+      const int Lcc = uniform(sh.cleg[cc]);
+      const VB same = onleg & (L == Lcc);
+      VB s01 = VB(false), s10 = VB(false), s11 = VB(false);
+      if (anypair) {
+        const int L1cc = uniform(sh.cleg1[cc]);
+        s01 = onleg1 & (L1 == Lcc);      // row's body2 leg meets this lane's body1 leg
+        s10 = onleg & (L == L1cc);       // row's body1 leg meets this lane's body2 leg
+        s11 = onleg1 & (L1 == L1cc);
+      }
+      vr a3[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const real* jr = jrow + (4 * cc + r) * kJRow;
+        vr a = jr[0] * xb[0] + jr[1] * xb[1] + jr[2] * xb[2] + jr[3] * xb[3] + jr[4] * xb[4] + jr[5] * xb[5];
+        a += sel(same, jr[6] * t[0] + jr[7] * t[1] + jr[8] * t[2], vr(real(0)));
         if (anypair) {
-          const int L1cc = uniform(sh.cleg1[cc]);
-          if (L1cc != L1prev) { pick(Bs1, L1cc); L1prev = L1cc; }
+          a += sel(s01, jr[6] * t1m[0] + jr[7] * t1m[1] + jr[8] * t1m[2], vr(real(0)));
+          a += sel(s10, jr[10] * t[0] + jr[11] * t[1] + jr[12] * t[2], vr(real(0)));
+          a += sel(s11, jr[10] * t1m[0] + jr[11] * t1m[1] + jr[12] * t1m[2], vr(real(0)));
         }
-        vr a3[3];
-#pragma unroll
-        for (int r = 0; r < 3; r++) {
-          const real* jr = jrow + (4 * cc + r) * kJRow;
-          vr a = jr[0] * B[0] + jr[1] * B[1] + jr[2] * B[2] + jr[3] * B[3] + jr[4] * B[4] + jr[5] * B[5];
-          a += jr[6] * Bs[0] + jr[7] * Bs[1] + jr[8] * Bs[2];
-          if (anypair) a += jr[10] * Bs1[0] + jr[11] * Bs1[1] + jr[12] * Bs1[2];
-          a3[r] = a;
-        }
-        A[4 * cc] = a3[0] + M.mu * a3[1];
-        A[4 * cc + 1] = a3[0] - M.mu * a3[1];
-        A[4 * cc + 2] = a3[0] + M.mu * a3[2];
-        A[4 * cc + 3] = a3[0] - M.mu * a3[2];
+        a3[r] = a;
       }
+      A[4 * cc] = a3[0] + M.mu * a3[1];
+      A[4 * cc + 1] = a3[0] - M.mu * a3[1];
+      A[4 * cc + 2] = a3[0] + M.mu * a3[2];
+      A[4 * cc + 3] = a3[0] - M.mu * a3[2];
     }
   }
-  // own diagonal entry (needed as 1/AR_ii): A_jj = J_j . B_j
-  vr Ajj = Jb[0] * B[0] + Jb[1] * B[1] + Jb[2] * B[2] + Jb[3] * B[3] + Jb[4] * B[4] + Jb[5] * B[5];
-#pragma unroll
-  for (int l = 0; l < 6; l++) Ajj += sel(L == l, Jl[0] * B[6 + 3 * l] + Jl[1] * B[7 + 3 * l] + Jl[2] * B[8 + 3 * l], vr(real(0)));
-  if (anypair)
-#pragma unroll
-    for (int l = 0; l < 6; l++) Ajj += sel(L1 == l, Jm[0] * B[6 + 3 * l] + Jm[1] * B[7 + 3 * l] + Jm[2] * B[8 + 3 * l], vr(real(0)));
+  // own diagonal entry (needed as 1/AR_ii)
+  vr Ajj = u[0] * xb[0] + u[1] * xb[1] + u[2] * xb[2] + u[3] * xb[3] + u[4] * xb[4] + u[5] * xb[5] + (Jl[0] * t[0] + Jl[1] * t[1] + Jl[2] * t[2]);
+  if (anypair) Ajj += Jm[0] * t1m[0] + Jm[1] * t1m[1] + Jm[2] * t1m[2];   // the two bodies of a pair are different legs
   vr ARjj = Ajj + Rr;
   vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
 
