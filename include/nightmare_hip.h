@@ -119,6 +119,12 @@ int nm_set_ablation(nm_env* env, int32_t mask);
 int nm_policy_forward(const float* obs_dev, int32_t num_envs, const float* const* weights_dev, const float* const* bias_dev,
                       const int32_t* dims, int32_t n_layers, float* actions_dev, void* stream);
 
+/* The same in two halves, for weights that stay fixed over many calls (a rollout, play.py): nm_policy_pack repacks the
+ * weights for the fused kernel (networks of <= 4 layers, <= 256 units; one packed network per process),
+ * nm_policy_forward_packed runs the last packed network - one launch per policy step. */
+int nm_policy_pack(const float* const* weights_dev, const float* const* bias_dev, const int32_t* dims, int32_t n_layers, void* stream);
+int nm_policy_forward_packed(const float* obs_dev, int32_t num_envs, float* actions_dev, void* stream);
+
 /* GAE(lambda) returns of one rollout (rsl_rl v1.0.2 RolloutStorage.compute_returns; caller reference train.py:54).
  * rewards/values/returns [T,N] f32, dones [T,N] u8, last_values [N] f32, all device memory. */
 int nm_gae(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev,

@@ -145,34 +145,65 @@ static size_t g_scratch_n = 0;
 static int g_scratch_dev = -1;
 extern "C" int nm_policy_set_error(const char* m);
 
+static MlpArgs g_packed;          // layer table of the last nm_policy_pack (device pointers into g_wt / the caller's biases)
+static bool g_packed_ok = false;
+static int g_packed_dev = -1;
+
+static bool mlp_fits(const int32_t* dims, int32_t n_layers) {
+  bool fits = n_layers <= kMaxLayers;
+  for (int l = 0; l <= n_layers && fits; l++) fits = dims[l] > 0 && dims[l] <= kMaxDim;
+  return fits;
+}
+
+extern "C" int nm_policy_pack(const float* const* weights, const float* const* bias, const int32_t* dims, int32_t n_layers, void* stream) {
+  if (!weights || !bias || !dims || n_layers <= 0) return nm_policy_set_error("nm_policy_pack: bad argument");
+  if (!mlp_fits(dims, n_layers)) return nm_policy_set_error("nm_policy_pack: network too large for the fused kernel (<= 4 layers of <= 256 units)");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_pack: no HIP device");
+  g_packed_ok = false;
+  MlpArgs a;
+  a.n_layers = n_layers; a.N = 0;
+  size_t tot = 0;
+  for (int l = 0; l < n_layers; l++) tot += (size_t)((dims[l] + 63) & ~63) * dims[l + 1];
+  if (tot > g_wt_n || dev != g_wt_dev) {
+    if (g_wt) (void)hipFree(g_wt);
+    g_wt = nullptr; g_wt_n = 0;
+    if (hipMalloc((void**)&g_wt, tot * sizeof(float)) != hipSuccess) return nm_policy_set_error("nm_policy_pack: hipMalloc failed");
+    g_wt_n = tot; g_wt_dev = dev;
+  }
+  size_t off = 0;
+  for (int l = 0; l < n_layers; l++) {
+    int kpad = (dims[l] + 63) & ~63, n = kpad * dims[l + 1];
+    hipLaunchKernelGGL(k_transpose_pad, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights[l], g_wt + off, dims[l + 1], dims[l], kpad);
+    a.w[l] = g_wt + off; a.b[l] = bias[l];
+    off += n;
+  }
+  for (int l = 0; l <= n_layers; l++) a.dims[l] = dims[l];
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_pack: launch failed");
+  g_packed = a; g_packed_ok = true; g_packed_dev = dev;
+  return 0;
+}
+
+extern "C" int nm_policy_forward_packed(const float* obs, int32_t N, float* actions, void* stream) {
+  if (!obs || !actions || N <= 0) return nm_policy_set_error("nm_policy_forward_packed: bad argument");
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_forward_packed: no HIP device");
+  if (!g_packed_ok || dev != g_packed_dev) return nm_policy_set_error("nm_policy_forward_packed: no packed network on this device (call nm_policy_pack)");
+  MlpArgs a = g_packed;
+  a.N = N;
+  hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(256), 0, (hipStream_t)stream, obs, actions, a);
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward_packed: launch failed");
+  return 0;
+}
+
 extern "C" int nm_policy_forward(const float* obs, int32_t N, const float* const* weights, const float* const* bias, const int32_t* dims,
                                  int32_t n_layers, float* actions, void* stream) {
   if (!obs || !weights || !bias || !dims || !actions || N <= 0 || n_layers <= 0) return nm_policy_set_error("nm_policy_forward: bad argument");
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_forward: no HIP device");
-  bool fits = n_layers <= kMaxLayers;
-  for (int l = 0; l <= n_layers && fits; l++) fits = dims[l] > 0 && dims[l] <= kMaxDim;
-  if (fits) {
-    MlpArgs a;
-    a.n_layers = n_layers; a.N = N;
-    size_t tot = 0;
-    for (int l = 0; l < n_layers; l++) tot += (size_t)((dims[l] + 63) & ~63) * dims[l + 1];
-    if (tot > g_wt_n || dev != g_wt_dev) {
-      if (g_wt) (void)hipFree(g_wt);
-      if (hipMalloc((void**)&g_wt, tot * sizeof(float)) != hipSuccess) return nm_policy_set_error("nm_policy_forward: hipMalloc failed");
-      g_wt_n = tot; g_wt_dev = dev;
-    }
-    size_t off = 0;
-    for (int l = 0; l < n_layers; l++) {
-      int kpad = (dims[l] + 63) & ~63, n = kpad * dims[l + 1];
-      hipLaunchKernelGGL(k_transpose_pad, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights[l], g_wt + off, dims[l + 1], dims[l], kpad);
-      a.w[l] = g_wt + off; a.b[l] = bias[l];
-      off += n;
-    }
-    for (int l = 0; l <= n_layers; l++) a.dims[l] = dims[l];
-    hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(256), 0, (hipStream_t)stream, obs, actions, a);
-    if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward: launch failed");
-    return 0;
+  if (mlp_fits(dims, n_layers)) {
+    if (nm_policy_pack(weights, bias, dims, n_layers, stream)) return 1;
+    return nm_policy_forward_packed(obs, N, actions, stream);
   }
   size_t maxh = 0;
   for (int l = 1; l < n_layers; l++) maxh = (size_t)dims[l] > maxh ? (size_t)dims[l] : maxh;

@@ -8,6 +8,8 @@ from . import _lib
 
 
 class ActorMLP(torch.nn.Module):
+    _packed = None   # (id of the network whose weights sit in the library's packed buffer, its version key)
+
     def __init__(self, dims=(66, 256, 256, 18)):
         super().__init__()
         self.dims = list(dims)
@@ -42,6 +44,15 @@ class ActorMLP(torch.nn.Module):
             obs = obs.contiguous().float()
         self._bind(obs.shape[0], obs.device)
         stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        _lib.check(L.nm_policy_forward(obs.data_ptr(), obs.shape[0], self._w, self._b, self._dims, len(self.layers),
-                                       self._out.data_ptr(), stream))
+        if max(self.dims) > 256 or len(self.layers) > 4:     # per-layer kernels
+            _lib.check(L.nm_policy_forward(obs.data_ptr(), obs.shape[0], self._w, self._b, self._dims, len(self.layers),
+                                           self._out.data_ptr(), stream))
+            return self._out
+        # weights are repacked for the fused kernel only when they changed (in-place updates bump tensor versions) or when
+        # another network was packed in between: a rollout pays one launch per policy step
+        ver = (self._key, tuple(p._version for l in self.layers for p in (l.weight, l.bias)))
+        if ActorMLP._packed != (id(self), ver):
+            _lib.check(L.nm_policy_pack(self._w, self._b, self._dims, len(self.layers), stream))
+            ActorMLP._packed = (id(self), ver)
+        _lib.check(L.nm_policy_forward_packed(obs.data_ptr(), obs.shape[0], self._out.data_ptr(), stream))
         return self._out
