@@ -176,6 +176,9 @@ template <class real> struct Env : nm_env {
     return 0;
   }
   ~Env() override {
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();   // kernels of this env may still be in flight on the caller's stream
+    for (auto& ev : prof_ev) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
     for (void* p : allocs) (void)hipFree(p);
   }
   int finalize(float* ep_stats, float* time_outs, hipStream_t s) {
