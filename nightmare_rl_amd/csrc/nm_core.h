@@ -1304,8 +1304,12 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr f = sel(act & (jar < vr(real(0))), -Dd * jar, vr(real(0)));
   vr g = bb;  // g_j = (A f)_j + b_j  (residual without the R term)
 #pragma unroll
-  for (int i = 0; i < kMaxRow; i++)
-    if (i < nefc) g += A[i] * rdlane(f, i);
+  for (int cc = 0; cc < kMaxCon; cc++) {
+    if (cc < ncon) {   // one uniform branch per contact (4 rows), not per row
+#pragma unroll
+      for (int r = 0; r < 4; r++) g += A[4 * cc + r] * rdlane(f, 4 * cc + r);
+    }
+  }
   {
     real cost = wsum<real>(sel(act, f * (bb + real(0.5) * (g - bb + Rr * f)), vr(real(0))));
     if (cost > real(0)) { f = vr(real(0)); g = bb; }
@@ -1355,8 +1359,12 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     const VB even = (lv & 1) == 0;
     vr Amq = vr(real(0));  // A[2p][2p+1], the even lane's copy in both lanes
 #pragma unroll
-    for (int p = 0; p < kMaxRow / 2; p++)
-      if (2 * p < nefc) Amq = sel(lv == 2 * p, A[2 * p + 1], Amq);
+    for (int cc = 0; cc < kMaxCon; cc++) {
+      if (cc < ncon) {
+        Amq = sel(lv == 4 * cc, A[4 * cc + 1], Amq);
+        Amq = sel(lv == 4 * cc + 2, A[4 * cc + 3], Amq);
+      }
+    }
     Amq = sel(even, Amq, shfl_xor1(Amq));
     const vr Amm = Ajj, Aqq = shfl_xor1(Ajj);
     const vr K1 = Amm + Aqq - Amq - Amq;
@@ -1369,7 +1377,8 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       vr dcap = vr(real(0)), ccap = vr(real(0));
 #pragma unroll
       for (int p = 0; p < kMaxRow / 2; p++) {
-        if (2 * p < nefc) {
+        if ((p & 1) == 0 && !(p / 2 < ncon)) break;   // one uniform test per contact (two pairs)
+        {
           const vr oq = shfl_xor1(f), rq = shfl_xor1(g);
           const vr bcm = g - Amm * f - Amq * oq, bcq = rq - Amq * f - Aqq * oq;
           const vr mid = real(0.5) * (f + oq);
