@@ -22,6 +22,7 @@
 // All inter-stage traffic goes through ~6.6 KB of LDS per wave; HBM is touched once per env-step
 // (state in, state + obs out).
 #pragma once
+#include <type_traits>
 #include <stddef.h>
 
 #include "simt.h"
@@ -1067,6 +1068,17 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
 }
 
 // =========================================================================================  stage C
+// Runs f(0), f(1), ... f(ncon-1) with compile-time indices (the A matrix lives in registers, so row numbers must be constants)
+// as NESTED ifs: the first unused contact leaves the whole chain with one taken branch, instead of one skipped test per
+// remaining contact as a flat unrolled loop of `if (c < ncon)` would cost (a taken scalar branch is ~80 cycles here).
+template <int C, int N, class F> NM_FN void for_contacts(int ncon, F&& f) {
+  if constexpr (C < N) {
+    if (C < ncon) {
+      f(std::integral_constant<int, C>{});
+      for_contacts<C + 1, N>(ncon, f);
+    }
+  }
+}
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
 template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep) {
   typedef V<real> vr;
@@ -1274,7 +1286,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
         s11 = onleg1 & (L1 == L1cc);
       }
       vr a3[3];
-#pragma unroll
+  #pragma unroll
       for (int r = 0; r < 3; r++) {
         const real* jr = jrow + (4 * cc + r) * kJRow;
         vr a = jr[0] * xb[0] + jr[1] * xb[1] + jr[2] * xb[2] + jr[3] * xb[3] + jr[4] * xb[4] + jr[5] * xb[5];
@@ -1303,13 +1315,11 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr jar = jaw - aref;
   vr f = sel(act & (jar < vr(real(0))), -Dd * jar, vr(real(0)));
   vr g = bb;  // g_j = (A f)_j + b_j  (residual without the R term)
+  for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
+    constexpr int cc = decltype(ccT)::value;
 #pragma unroll
-  for (int cc = 0; cc < kMaxCon; cc++) {
-    if (cc < ncon) {   // one uniform branch per contact (4 rows), not per row
-#pragma unroll
-      for (int r = 0; r < 4; r++) g += A[4 * cc + r] * rdlane(f, 4 * cc + r);
-    }
-  }
+    for (int r = 0; r < 4; r++) g += A[4 * cc + r] * rdlane(f, 4 * cc + r);
+  });
   {
     real cost = wsum<real>(sel(act, f * (bb + real(0.5) * (g - bb + Rr * f)), vr(real(0))));
     if (cost > real(0)) { f = vr(real(0)); g = bb; }
@@ -1325,25 +1335,23 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     // f after the sweep; the other lanes only need the delta, which reaches them through g.
     vr dcap = vr(real(0)), ccap = vr(real(0));
     const V<int> lv = opaque_lane();
+    for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
+      constexpr int cc = decltype(ccT)::value;
 #pragma unroll
-    for (int cc = 0; cc < kMaxCon; cc++) {
-      if (cc < ncon) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = 4 * cc + r;
-          vr res = g + Rr * f;
-          vr fn = vmax(f - res * ARinv, vr(real(0)));
-          vr dl = fn - f;
-          vr change = dl * (hA * dl + res);          // 0.5 dl^2 AR_ii + dl res
-          VB bad = change > vr(real(1e-10));         // costChange: revert an update that does not decrease the cost
-          dl = sel(bad, vr(real(0)), dl);
-          g += A[i] * rdlane(dl, i);
-          VB me = lv == i;
-          dcap = sel(me, dl, dcap);
-          ccap = sel(me & !bad, change, ccap);
-        }
+      for (int r = 0; r < 4; r++) {
+        const int i = 4 * cc + r;
+        vr res = g + Rr * f;
+        vr fn = vmax(f - res * ARinv, vr(real(0)));
+        vr dl = fn - f;
+        vr change = dl * (hA * dl + res);          // 0.5 dl^2 AR_ii + dl res
+        VB bad = change > vr(real(1e-10));         // costChange: revert an update that does not decrease the cost
+        dl = sel(bad, vr(real(0)), dl);
+        g += A[i] * rdlane(dl, i);
+        VB me = lv == i;
+        dcap = sel(me, dl, dcap);
+        ccap = sel(me & !bad, change, ccap);
       }
-    }
+    });
     f = f + dcap;
     sh.it_pgs = iter + 1;
     if (-wsum<real>(ccap) * M.pgs_scale < M.pgs_tol) break;
@@ -1358,13 +1366,11 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     const V<int> lvp = lv >> 1;
     const VB even = (lv & 1) == 0;
     vr Amq = vr(real(0));  // A[2p][2p+1], the even lane's copy in both lanes
-#pragma unroll
-    for (int cc = 0; cc < kMaxCon; cc++) {
-      if (cc < ncon) {
-        Amq = sel(lv == 4 * cc, A[4 * cc + 1], Amq);
-        Amq = sel(lv == 4 * cc + 2, A[4 * cc + 3], Amq);
-      }
-    }
+    for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
+      constexpr int cc = decltype(ccT)::value;
+      Amq = sel(lv == 4 * cc, A[4 * cc + 1], Amq);
+      Amq = sel(lv == 4 * cc + 2, A[4 * cc + 3], Amq);
+    });
     Amq = sel(even, Amq, shfl_xor1(Amq));
     const vr Amm = Ajj, Aqq = shfl_xor1(Ajj);
     const vr K1 = Amm + Aqq - Amq - Amq;
