@@ -1610,7 +1610,7 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
   for (int e = 0; e < G; e++) {
     if (rdlane(sel(gbad, V<int>(1), V<int>(0)), 8 * e) != 0) {
       Sh<real>& sh = w.e[e];
-      const V<int> lane = lane_id();
+      const V<int> lane = opaque_lane();   // cold path: keep its address math out of the hot loop's live ranges
       sh.nwarn += 1;
       vr q0 = ldsv(M.qpos0, sel(lane < kNQ, lane, V<int>(0)));
       real vz = -M.grav * M.h;
@@ -1627,7 +1627,7 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
 }
 
 template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) {  // mj_resetData
-  const V<int> lane = lane_id();
+  const V<int> lane = opaque_lane();
   stsv(sh.qpos, lane, ldsv(M.qpos0, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
   stsv(sh.qvel, lane, real(0), lane < kNV);
   stsv(sh.warm, lane, real(0), lane < kNV);
