@@ -1675,19 +1675,36 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   const V<int> lane = opaque_lane();   // index math stays local to this function (not kept live across the physics)
   const VB l18 = lane < kNU;
   const V<int> l18c = sel(l18, lane, V<int>(0));
-  // ---- load state
-  stsv(sh.qpos, lane, gldv(A.qpos, sel(lane < kNQ, lane, V<int>(0)) + env * kNQ), lane < kNQ);
-  stsv(sh.qvel, lane, gldv(A.qvel, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
-  stsv(sh.warm, lane, gldv(A.qwarm, sel(lane < kNV, lane, V<int>(0)) + env * kNV), lane < kNV);
+  // ---- every HBM read of this env-step is issued here, back to back, before the first LDS store (a masked store is a
+  // branch: loads placed after one would each wait for their own round trip)
+  const vr q_in = gldv(A.qpos, sel(lane < kNQ, lane, V<int>(0)) + env * kNQ);
+  const vr v_in = gldv(A.qvel, sel(lane < kNV, lane, V<int>(0)) + env * kNV);
+  const vr w_in = gldv(A.qwarm, sel(lane < kNV, lane, V<int>(0)) + env * kNV);
+  const V<int> hc_in = gldv(A.hullcache, sel(lane < 8, lane, V<int>(0)) + env * 8);
+  const V<float> a_in = gldv(A.actions, l18c + env * kNU);
+  vr cmd_in = vr(real(0)), eps_in = vr(real(0)), prev_act = vr(real(0)), prev_dofvel = vr(real(0)), dofpos_old = vr(real(0));
+  int64_t ep = 0;
+  uint32_t ctr_in = 0;
+  if (!A.physics_only) {   // what the epilogue needs from HBM is fetched now, under the physics, not when it is needed
+    cmd_in = gldv(A.cmd, sel(lane < 3, lane, V<int>(0)) + env * 3);
+    eps_in = gldv(A.epsum, sel(lane < kNREW, lane, V<int>(0)) + env * kNREW);
+    ep = gld1(A.eplen, env);
+    ctr_in = gld1(A.rngctr, env);
+    prev_act = gldv(A.act, l18c + env * kNU);
+    prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
+    dofpos_old = gldv(A.dofpos, l18c + env * kNU);
+  }
+  stsv(sh.qpos, lane, q_in, lane < kNQ);
+  stsv(sh.qvel, lane, v_in, lane < kNV);
+  stsv(sh.warm, lane, w_in, lane < kNV);
+  stsv(sh.hcache, lane, hc_in, lane < 8);
   sh.nwarn = 0;
   sh.nfallback = 0;
   sh.nhop = 0;
-  stsv(sh.hcache, lane, gldv(A.hullcache, sel(lane < 8, lane, V<int>(0)) + env * 8), lane < 8);
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
-  V<float> a_in = gldv(A.actions, l18c + env * kNU);
   V<float> af = a_in * M.action_scale;
   af = vmin(vmax(af, V<float>(-M.clip_actions)), V<float>(M.clip_actions));
-  vr act, prev_act = vr(real(0)), prev_dofvel = vr(real(0)), dofpos_old;
+  vr act;
   vr defp;
   {
     V<int> m3 = lane % 3;
@@ -1699,20 +1716,14 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   act = (real)af;
 #endif
   if (!A.physics_only) {
-    // what the epilogue needs from HBM is fetched now, under the physics, not when it is needed
-    stsv(sh.ecmd, lane, gldv(A.cmd, sel(lane < 3, lane, V<int>(0)) + env * 3), lane < 3);
-    stsv(sh.eepsum, lane, gldv(A.epsum, sel(lane < kNREW, lane, V<int>(0)) + env * kNREW), lane < kNREW);
-    {
-      const int64_t ep = gld1(A.eplen, env);
-      sh.eplen_lo = (int)(uint32_t)(ep & 0xffffffffll);
-      sh.eplen_hi = (int)(ep >> 32);
-      sh.ectr = gld1(A.rngctr, env);
-    }
-    prev_act = gldv(A.act, l18c + env * kNU);
-    prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
-    dofpos_old = gldv(A.dofpos, l18c + env * kNU);
+    stsv(sh.ecmd, lane, cmd_in, lane < 3);
+    stsv(sh.eepsum, lane, eps_in, lane < kNREW);
+    sh.eplen_lo = (int)(uint32_t)(ep & 0xffffffffll);
+    sh.eplen_hi = (int)(ep >> 32);
+    sh.ectr = ctr_in;
     stsv(sh.ctrl, lane, ((act - defp) - dofpos_old) * M.p_gain, l18);
   } else {  // dynamics-only mode (BASELINE config 2): same PD law on the current joint angles, no env buffers
+    wave_sync();
     stsv(sh.ctrl, lane, ((act - defp) - ldsv(sh.qpos, l18c + 7)) * M.p_gain, l18);
   }
   // carried to the epilogue through LDS, not in registers: nothing stays live across the physics
