@@ -1746,10 +1746,15 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     defp = sel(m3 == 1, vr(M.default_pos[1]), sel(m3 == 0, vr(M.default_pos[0]), vr(M.default_pos[2])));
   }
   // ---- store physics state
-  gstv(A.hullcache, lane + env * 8, ldsv(sh.hcache, sel(lane < 8, lane, V<int>(0))), lane < 8);
-  gstv(A.qpos, lane + env * kNQ, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
-  gstv(A.qvel, lane + env * kNV, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
-  gstv(A.qwarm, lane + env * kNV, ldsv(sh.warm, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
+  {  // LDS reads first, then the (branchy, masked) global stores: one LDS round trip for the four of them
+    const V<int> hc = ldsv(sh.hcache, sel(lane < 8, lane, V<int>(0)));
+    const vr q = ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), v = ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))),
+             w = ldsv(sh.warm, sel(lane < kNV, lane, V<int>(0)));
+    gstv(A.hullcache, lane + env * 8, hc, lane < 8);
+    gstv(A.qpos, lane + env * kNQ, q, lane < kNQ);
+    gstv(A.qvel, lane + env * kNV, v, lane < kNV);
+    gstv(A.qwarm, lane + env * kNV, w, lane < kNV);
+  }
   if (A.rec && env == A.rec_env) {
     gstv(A.rec, lane, ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0))), lane < kNQ);
     gstv(A.rec, lane + kNQ, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
