@@ -59,7 +59,10 @@ class ActorCritic(nn.Module):
 
     def act(self, observations, **kwargs):
         self.update_distribution(observations)
-        return self.distribution.sample()
+        # mean + std * N(0,1): the same draw as Normal.sample(), written with randn_like because torch.normal(tensor, tensor)
+        # cannot be captured into a HIP graph on this stack (the runner replays the whole rollout as one graph)
+        d = self.distribution
+        return (d.mean + d.stddev * torch.randn_like(d.mean)).detach()
 
     def get_actions_log_prob(self, actions):
         return self.distribution.log_prob(actions).sum(dim=-1)

@@ -60,34 +60,90 @@ class OnPolicyRunner:
         log = self.log_dir is not None and _rank() == 0
         if log:
             os.makedirs(self.log_dir, exist_ok=True)
+        T = self.num_steps_per_env
+        fin = torch.zeros(3, device=dev)         # finished episodes this iteration: sum of returns, sum of lengths, count
+        ep_acc = None                            # running sum of extras['episode'] over the steps of one rollout
+        state = {"obs": obs, "critic_obs": critic_obs, "ep_keys": None}
+
+        def rollout():
+            """One rollout of T steps. Nothing in here reads device memory from the host, shapes and buffers are the same every
+            iteration, so on a GPU the whole thing (policy, sampling, env kernels, storage writes, statistics) is captured once
+            into a HIP graph and replayed."""
+            nonlocal ep_acc
+            o, co = state["obs"], state["critic_obs"]
+            fin.zero_()
+            if ep_acc is not None:
+                ep_acc.zero_()
+            for _ in range(T):
+                actions = alg.act(o, co)
+                o, priv_, rewards, dones, infos = env.step(actions)
+                o, rewards, dones = o.to(dev), rewards.to(dev), dones.to(dev)
+                co = priv_.to(dev) if priv_ is not None else o
+                alg.process_env_step(rewards, dones, infos)
+                cur_ret.add_(rewards)
+                cur_len.add_(1)
+                d = (dones > 0).float()
+                fin.add_(torch.stack([(cur_ret * d).sum(), (cur_len * d).sum(), d.sum()]))
+                cur_ret.mul_(1 - d)
+                cur_len.mul_(1 - d)
+                if "episode" in infos:
+                    keys = sorted(infos["episode"])
+                    e = torch.stack([infos["episode"][k].float() for k in keys])
+                    if ep_acc is None:
+                        ep_acc = torch.zeros_like(e)
+                    ep_acc.add_(e)
+                    state["ep_keys"] = keys
+            state["obs"], state["critic_obs"] = o, co
+
+        want_graph = bool(self.cfg.get("graph_rollout", True)) and torch.device(dev).type == "cuda" and hasattr(env, "_h") \
+            and not getattr(env, "add_noise", False) and not getattr(getattr(env.cfg, "viewer", None), "record_states", False)
+        graph = None
+        on_gpu = torch.device(dev).type == "cuda"
+        ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else (None, None)
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
-            fin = torch.zeros(3, device=dev)     # finished episodes this iteration: sum of returns, sum of lengths, count
-            ep_stats, ep_n = None, 0
+            if on_gpu:
+                ev0.record()
             with torch.inference_mode():
-                for _ in range(self.num_steps_per_env):
-                    actions = alg.act(obs, critic_obs)
-                    obs, priv, rewards, dones, infos = env.step(actions)
-                    obs, rewards, dones = obs.to(dev), rewards.to(dev), dones.to(dev)
-                    critic_obs = priv.to(dev) if priv is not None else obs
-                    alg.process_env_step(rewards, dones, infos)
-                    cur_ret += rewards
-                    cur_len += 1
-                    d = (dones > 0).float()
-                    fin += torch.stack([(cur_ret * d).sum(), (cur_len * d).sum(), d.sum()])
-                    cur_ret *= 1 - d
-                    cur_len *= 1 - d
-                    if "episode" in infos:
-                        e = torch.stack([infos["episode"][k].float() for k in sorted(infos["episode"])])
-                        ep_stats = e.clone() if ep_stats is None else ep_stats + e
-                        ep_n += 1
+                if graph is not None:
+                    graph.replay()
+                    alg.storage.step = T         # what the captured add_transitions calls did on the host side
+                    env.common_step_counter += T
+                elif want_graph and it > self.current_learning_iteration and ep_acc is not None:
+                    # the first iteration ran eagerly (lazy initialisations done, buffers exist): capture the next one
+                    try:
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            rollout()
+                        graph = g               # the capture did not execute anything: run this iteration from the graph
+                        alg.storage.clear()
+                        graph.replay()
+                        alg.storage.step = T
+                    except Exception as exc:     # keep training on the eager path
+                        want_graph = False
+                        alg.storage.clear()
+                        if log:
+                            print(f"rollout graph capture failed ({type(exc).__name__}: {exc}); staying on the eager path", flush=True)
+                        rollout()
+                else:
+                    rollout()
+                obs, critic_obs = state["obs"], state["critic_obs"]
+                ep_stats, ep_n = (ep_acc, T) if ep_acc is not None else (None, 0)
+                infos = env.extras
+                if on_gpu:
+                    ev1.record()             # the rollout is asynchronous: its device time is read after the update has synchronised
                 collection_time = time.time() - start
-                start = time.time()
                 step_rew = alg.storage.rewards.mean()
                 alg.compute_returns(critic_obs)
             mean_value_loss, mean_surrogate_loss = alg.update()
             kl = getattr(alg, "last_kl", float("nan"))
-            learn_time = time.time() - start
+            total_time = time.time() - start
+            if on_gpu:
+                torch.cuda.synchronize()
+                total_time = time.time() - start
+                collection_time = ev0.elapsed_time(ev1) * 1e-3
+            learn_time = max(total_time - collection_time, 0.0)
             if _world() > 1:
                 dist.all_reduce(fin)
             if _world() > 1:
@@ -103,8 +159,8 @@ class OnPolicyRunner:
             rec = dict(it=it, fps=steps / (collection_time + learn_time), collection_time=collection_time, learn_time=learn_time,
                        value_loss=mean_value_loss, surrogate_loss=mean_surrogate_loss, kl=kl, mean_reward=mean_ret, mean_episode_length=mean_len, mean_step_reward=f[3],
                        action_std=float(alg.actor_critic.std.detach().mean()), lr=alg.learning_rate, total_timesteps=self.tot_timesteps)
-            if ep_stats is not None and "episode" in infos:
-                for k, v in zip(sorted(infos["episode"]), (ep_stats / max(ep_n, 1)).tolist()):
+            if ep_stats is not None and state["ep_keys"]:
+                for k, v in zip(state["ep_keys"], (ep_stats / max(ep_n, 1)).tolist()):
                     rec["episode/" + k] = v
             self.history.append(rec)
             if log:
