@@ -85,7 +85,12 @@ class RolloutStorage:
         obs = self.observations.flatten(0, 1)
         cobs = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else obs
         flat = [t.flatten(0, 1) for t in (self.actions, self.values, self.advantages, self.returns, self.actions_log_prob, self.mu, self.sigma)]
+        # one gather of the whole buffer per update instead of one per mini-batch and epoch: the permutation is drawn once
+        # (as upstream), so every epoch sees the same mini-batches - contiguous slices of the permuted copy
+        obs_p = obs[idx]
+        cobs_p = cobs[idx] if self.privileged_observations is not None else obs_p
+        flat_p = [t[idx] for t in flat]
         for _ in range(num_epochs):
             for i in range(num_mini_batches):
-                b = idx[i * mb:(i + 1) * mb]
-                yield (obs[b], cobs[b]) + tuple(t[b] for t in flat) + ((None, None), None)
+                sl = slice(i * mb, (i + 1) * mb)
+                yield (obs_p[sl], cobs_p[sl]) + tuple(t[sl] for t in flat_p) + ((None, None), None)
