@@ -9,12 +9,43 @@ from torch.distributions import Normal
 _ACTIVATIONS = {"elu": nn.ELU, "selu": nn.SELU, "relu": nn.ReLU, "lrelu": nn.LeakyReLU, "tanh": nn.Tanh, "sigmoid": nn.Sigmoid}
 
 
+class _SplitKLinearFn(torch.autograd.Function):
+    """y = x W' + b whose weight gradient dW = dY' X is computed as a batched product over row chunks and then summed.
+    A PPO mini-batch has ~80 k rows and these layers are <= 66 wide: as one GEMM (K = 80 k, M x N tiny) the library runs a
+    handful of workgroups for 250 us; 128 chunks of 640 rows keep the whole GPU busy for a few microseconds."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, chunks):
+        ctx.save_for_backward(x, w)
+        ctx.chunks = chunks
+        return torch.nn.functional.linear(x, w, b)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        s = ctx.chunks
+        gx = gy @ w if ctx.needs_input_grad[0] else None
+        rows = x.shape[0] // s
+        gw = torch.bmm(gy.reshape(s, rows, gy.shape[1]).transpose(1, 2), x.reshape(s, rows, x.shape[1])).sum(dim=0)
+        return gx, gw, gy.sum(dim=0), None
+
+
+class SplitKLinear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) with the split-K weight gradient for tall inputs."""
+    CHUNKS, MIN_ROWS = 128, 16384
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and x.dim() == 2 and x.shape[0] >= self.MIN_ROWS and x.shape[0] % self.CHUNKS == 0 and self.weight.requires_grad:
+            return _SplitKLinearFn.apply(x, self.weight, self.bias, self.CHUNKS)
+        return super().forward(x)
+
+
 def _mlp(n_in, hidden, n_out, act):
     dims = [n_in] + list(hidden)
     layers = []
     for a, b in zip(dims[:-1], dims[1:]):
-        layers += [nn.Linear(a, b), act()]
-    layers.append(nn.Linear(dims[-1], n_out))
+        layers += [SplitKLinear(a, b), act()]
+    layers.append(SplitKLinear(dims[-1], n_out))
     return nn.Sequential(*layers)
 
 

@@ -135,3 +135,18 @@ def test_rollout_keeps_the_observation_the_policy_saw():
     torch.testing.assert_close(stored, torch.stack(seen))
     alg.actor_critic.act(stored.flatten(0, 1))
     torch.testing.assert_close(alg.actor_critic.action_mean, alg.storage.mu.flatten(0, 1))      # same weights -> same means: KL = 0
+
+
+def test_split_k_linear_gradients_match_nn_linear():
+    from nightmare_rl_amd.rl.actor_critic import SplitKLinear
+    torch.manual_seed(0)
+    a, b = SplitKLinear(66, 54), torch.nn.Linear(66, 54)
+    b.load_state_dict(a.state_dict())
+    x = torch.randn(SplitKLinear.MIN_ROWS, 66, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    (a(x).tanh().sum()).backward()
+    (b(x2).tanh().sum()).backward()
+    torch.testing.assert_close(a.weight.grad, b.weight.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(a.bias.grad, b.bias.grad, rtol=1e-4, atol=1e-4)
+    torch.testing.assert_close(x.grad, x2.grad, rtol=1e-5, atol=1e-6)
+    assert list(a.state_dict()) == ["weight", "bias"]
