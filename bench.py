@@ -59,6 +59,29 @@ def cpu_baseline(seconds_budget=15.0):
             "sample": f"{n} envs x {k} random-action steps from reset (fp64 C restatement of mj_step + env epilogue, OpenMP over envs)"}
 
 
+def cpu_baseline_detail(seconds_each=6.0):
+    """the CPU path at T = 1 and T = all cores, N = 1 and N = 4096 (the reference's own case is N = 1, T = 1)."""
+    from oracle import oracle as orc
+    out = {}
+    for n in (1, 4096):
+        for threads in (1, host_cores()):
+            if n == 1 and threads > 1:
+                continue
+            env = orc.OracleEnv(n, seed=0, num_threads=threads)
+            env.reset()
+            rng = np.random.default_rng(0)
+            acts = [rng.uniform(-1, 1, (n, 18)).astype(np.float32) for _ in range(8)]
+            for i in range(3):
+                env.step(acts[i % 8])
+            t0 = time.perf_counter()
+            k = 0
+            while time.perf_counter() - t0 < seconds_each:
+                env.step(acts[k % 8])
+                k += 1
+            out[f"N{n}_T{threads}"] = n * k / (time.perf_counter() - t0)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -66,6 +89,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-detail", action="store_true", help="also time the CPU oracle at N in {1, 4096} x T in {1, all cores} (adds ~20 s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -201,6 +225,8 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline()
+            if args.cpu_detail:
+                out["cpu_baseline"]["detail_env_steps_per_s"] = cpu_baseline_detail()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,6 +1,6 @@
 """Teacher-forced single-step error of the fp32 kernels against the fp64 oracle over many env-steps (diagnostic)."""
 import os, sys, numpy as np, torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config
 from nightmare_rl_amd.envs.nightmare_v3_env import NightmareV3Env
 from oracle import oracle as orc
