@@ -1343,13 +1343,14 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
         vr res = g + Rr * f;
         vr fn = vmax(f - res * ARinv, vr(real(0)));
         vr dl = fn - f;
-        vr change = dl * (hA * dl + res);          // 0.5 dl^2 AR_ii + dl res
-        VB bad = change > vr(real(1e-10));         // costChange: revert an update that does not decrease the cost
-        dl = sel(bad, vr(real(0)), dl);
+        // 0.5 dl^2 AR_ii + dl res. mj_solPGS reverts an update whose cost change exceeds +1e-10; for this projected
+        // coordinate step that cannot happen: unclamped, 0.5 AR dl + res = res (1 - 0.5 AR/AR~) has the sign of res = -sign(dl);
+        // clamped at zero, res >= AR f makes it -f (res - 0.5 AR f) <= 0 - no cancellation in either case, so no test.
+        vr change = dl * (hA * dl + res);
         g += A[i] * rdlane(dl, i);
         VB me = lv == i;
         dcap = sel(me, dl, dcap);
-        ccap = sel(me & !bad, change, ccap);
+        ccap = sel(me, change, ccap);
       }
     });
     f = f + dcap;
