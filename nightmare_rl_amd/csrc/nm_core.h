@@ -1359,9 +1359,12 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   }
   nm_stamp(6);
   // ---- mj_solNoSlip: per opposing pyramid pair (lanes 2p, 2p+1), exact 1-D minimisation along (f0 - f1) without R.
-  // Both lanes of a pair evaluate the update from their own side ("m" = mine, "q" = the partner, fetched by DPP): the new
-  // values are mid +- y with y clamped to [-mid, mid], which is mj_solNoSlip's three-way case split. What does not change
-  // between iterations (the pair's 2x2 block of A, 1/K1) is prepared once.
+  // mj_solNoSlip writes the pair's quadratic as 0.5 K1 y^2 + K0 y around mid = (f0 + f1)/2 with K1 = A00 + A11 - 2 A01 and
+  // K0 = mid (A00 - A11) + bc0 - bc1 (bc = residual without the pair's own forces). Substituting bc gives
+  // K0 = (g0 - g1) - 0.5 K1 (f0 - f1), so the new value of a lane is f - (g_mine - g_partner)/K1: a Newton step on the
+  // difference of the two residuals. The sum f0 + f1 is kept, hence d_partner = -d, the three-way case split of the
+  // reference is the clamp d in [-f_mine, f_partner], and the cost change is d (0.5 K1 d + (g_mine - g_partner)). Each lane
+  // evaluates its side with the partner's (f, g) from DPP; 1/K1 and 0.5 K1 are prepared once.
   {
     const V<int> lv = opaque_lane();
     const V<int> lvp = lv >> 1;
@@ -1373,11 +1376,9 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       Amq = sel(lv == 4 * cc + 2, A[4 * cc + 3], Amq);
     });
     Amq = sel(even, Amq, shfl_xor1(Amq));
-    const vr Amm = Ajj, Aqq = shfl_xor1(Ajj);
-    const vr K1 = Amm + Aqq - Amq - Amq;
-    const VB small = K1 < vr(real(1e-15));
-    const vr invK1 = vr(real(1)) / K1;
-    const vr dA = Amm - Aqq;
+    const vr K1 = Ajj + shfl_xor1(Ajj) - Amq - Amq;
+    const VB small = K1 < vr(real(1e-15));       // degenerate pair: both forces go to their mean
+    const vr invK1 = vr(real(1)) / K1, hK1 = real(0.5) * K1;
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       real improvement = real(0);
       if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
@@ -1386,17 +1387,11 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       for (int p = 0; p < kMaxRow / 2; p++) {
         if ((p & 1) == 0 && !(p / 2 < ncon)) break;   // one uniform test per contact (two pairs)
         {
-          const vr oq = shfl_xor1(f), rq = shfl_xor1(g);
-          const vr bcm = g - Amm * f - Amq * oq, bcq = rq - Amq * f - Aqq * oq;
-          const vr mid = real(0.5) * (f + oq);
-          const vr K0 = mid * dA + bcm - bcq;
-          vr y = vmin(vmax(-K0 * invK1, -mid), mid);
-          y = sel(small, vr(real(0)), y);
-          vr d = (mid + y) - f;
-          const vr dq = shfl_xor1(d);
-          const vr hm = d * (real(0.5) * (Amm * d + Amq * dq) + g);   // this lane's share of the cost change
-          const vr change = hm + shfl_xor1(hm);
-          const VB bad = change > vr(real(1e-10));
+          const vr oq = shfl_xor1(f), dg = g - shfl_xor1(g);
+          vr d = vmin(vmax(-dg * invK1, -f), oq);
+          d = sel(small, real(0.5) * (oq - f), d);
+          const vr change = d * (hK1 * d + dg);
+          const VB bad = change > vr(real(1e-10));     // costChange: revert an update that does not decrease the cost
           d = sel(bad, vr(real(0)), d);
           g += A[2 * p] * rdlane(d, 2 * p) + A[2 * p + 1] * rdlane(d, 2 * p + 1);
           const VB me = lvp == p;
