@@ -1341,8 +1341,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       for (int r = 0; r < 4; r++) {
         const int i = 4 * cc + r;
         vr res = g + Rr * f;
-        vr fn = vmax(f - res * ARinv, vr(real(0)));
-        vr dl = fn - f;
+        vr dl = vmax(-res * ARinv, -f);              // = max(f - res/AR_ii, 0) - f
         // 0.5 dl^2 AR_ii + dl res. mj_solPGS reverts an update whose cost change exceeds +1e-10; for this projected
         // coordinate step that cannot happen: unclamped, 0.5 AR dl + res = res (1 - 0.5 AR/AR~) has the sign of res = -sign(dl);
         // clamped at zero, res >= AR f makes it -f (res - 0.5 AR f) <= 0 - no cancellation in either case, so no test.
