@@ -57,6 +57,8 @@ def main():
         print(f"Loading model from: {path}")
         runner.load(path)
     runner.learn(num_learning_iterations=args.iters if args.iters is not None else train_cfg.runner.max_iterations, init_at_random_ep_len=True)
+    if rank == 0:
+        print("env counters:", env.counters(), flush=True)   # contacts dropped by the per-env cap, MuJoCo-style bad-state resets
     if world > 1:
         dist.destroy_process_group()
 
