@@ -2,7 +2,7 @@
 // play.py:122, train.py:40) as a batched GEMM chain on the matrix cores: exact-f32 MFMA (v_mfma_f32_32x32x2_f32),
 // bias + ELU fused into the accumulator epilogue.
 //
-// Fused path (all dims <= 256, <= 4 layers): one workgroup of 4 waves owns 32 envs; activations ping-pong between two
+// Fused path (all dims <= 256, <= 4 layers): one workgroup of 8 waves owns 16 envs; activations ping-pong between two
 // padded LDS tiles, weights stream from L2 as one 16-byte load per lane per 4 k-steps; a wave computes 32x32 output
 // tiles. One launch per policy step. Layers that do not fit use the per-layer kernel.
 #include <hip/hip_runtime.h>
@@ -30,19 +30,20 @@ struct MlpArgs {
   int n_layers, N;
 };
 
-// One workgroup (4 waves) owns 16 envs; activations ping-pong between two padded LDS tiles. A wave computes 16x16 output
+// One workgroup (8 waves, two per SIMD) owns 16 envs; activations ping-pong between two padded LDS tiles. A wave computes 16x16 output
 // tiles with v_mfma_f32_16x16x4_f32 (exact f32), TWO tiles at a time so the two accumulator chains hide the 40-cycle
 // dependent latency behind the 32-cycle issue interval. Lane (r = l&15, q = l>>4) feeds A[i=r][k=k0+q], B[k=k0+q][j=r].
-__global__ void __launch_bounds__(256) k_mlp_fused(const float* __restrict__ obs, float* __restrict__ out, MlpArgs a) {
+constexpr int kMlpThreads = 512;   // 8 waves: one pass over the 16 column tiles of a 256-wide layer, two waves per SIMD
+__global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restrict__ obs, float* __restrict__ out, MlpArgs a) {
   __shared__ float act[2][kTileRows * kLd];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * kTileRows;
-  for (int i = tid; i < 2 * kTileRows * kLd; i += 256) (&act[0][0])[i] = 0.0f;   // padded k-columns must be finite
+  for (int i = tid; i < 2 * kTileRows * kLd; i += kMlpThreads) (&act[0][0])[i] = 0.0f;   // padded k-columns must be finite
   __syncthreads();
   {  // stage the observation tile (coalesced rows)
     const int K = a.dims[0];
-    for (int i = tid; i < kTileRows * K; i += 256) {
+    for (int i = tid; i < kTileRows * K; i += kMlpThreads) {
       int rr = i / K, kk = i - rr * K;
       act[0][rr * kLd + kk] = (row0 + rr < a.N) ? obs[(size_t)(row0 + rr) * K + kk] : 0.0f;
     }
@@ -56,7 +57,7 @@ __global__ void __launch_bounds__(256) k_mlp_fused(const float* __restrict__ obs
     const float* xrow = act[l & 1] + r * kLd;
     float* y = act[(l + 1) & 1];
     const int ntile = (O + 15) / 16, nch = (K + 63) >> 6;
-    for (int t = wave * 2; t < ntile; t += 8) {   // this wave: tiles t and t+1
+    for (int t = wave * 2; t < ntile; t += 2 * (kMlpThreads / 64)) {   // this wave: tiles t and t+1
       const int c0 = t * 16 + r, c1 = c0 + 16;
       const bool ok0 = c0 < O, ok1 = c1 < O;
       const float* w0 = Wt + (ok0 ? c0 : 0);
@@ -191,7 +192,7 @@ extern "C" int nm_policy_forward_packed(const float* obs, int32_t N, float* acti
   if (!g_packed_ok || dev != g_packed_dev) return nm_policy_set_error("nm_policy_forward_packed: no packed network on this device (call nm_policy_pack)");
   MlpArgs a = g_packed;
   a.N = N;
-  hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(256), 0, (hipStream_t)stream, obs, actions, a);
+  hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(kMlpThreads), 0, (hipStream_t)stream, obs, actions, a);
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward_packed: launch failed");
   return 0;
 }
