@@ -15,7 +15,7 @@ extern "C" {
 
 #define NM_NUM_OBS 66      /* envs/nightmare_v3_config.py:11 */
 #define NM_NUM_ACTIONS 18  /* envs/nightmare_v3_config.py:13 */
-#define NM_NUM_REWARDS 8   /* non-zero reward scales, envs/nightmare_v3_config.py:78-86 */
+#define NM_NUM_REWARDS 16  /* reward names of envs/nightmare_v3_config.py:78-96 that have a _reward_ function (envs/nightmare_v3_env.py:399-497) */
 #define NM_DTYPE_F32 0
 #define NM_DTYPE_F64 1     /* verification build of the same kernels in double */
 
@@ -37,12 +37,20 @@ typedef struct {
   double max_lin_vel_x, max_ang_vel;/* commands.ranges :62,:64 */
   double termination_contact_force; /* env.termination_contact_force :22 */
   double tracking_sigma;            /* rewards.tracking_sigma :98 */
-  double reward_scales[NM_NUM_REWARDS];
+  double reward_scales[NM_NUM_REWARDS]; /* rewards.scales :78-95; 0 drops the term from the reward table (env.py:123-128) */
+  int32_t tibia_contact_mode;       /* env.tibia_contact_mode :18  0 ignore, 1 penalise, 2 terminate (env.py:248-251,479-485) */
+  double tibia_max_contact_force;   /* env.tibia_max_contact_force :19 */
+  int32_t body_contact_mode;        /* env.body_contact_mode :20 */
+  double body_max_contact_force;    /* env.body_max_contact_force :21 */
+  double base_height_target;        /* rewards.base_height_target :99 */
+  double max_contact_force;         /* rewards.max_contact_force :100 */
 } nm_config;
 
 void nm_default_config(nm_config* cfg);
-/* "action_rate", "body_contact_forces", "default_position", "dof_acc", "orientation", "tracking_ang_vel",
- * "tracking_lin_vel", "termination": the order rewards are evaluated in (envs/nightmare_v3_env.py:132-137, 285) */
+/* "action_rate", "ang_vel_xy", "base_height", "body_contact_forces", "default_position", "dof_acc", "dof_vel", "feet_air_time",
+ * "feet_contact_forces", "lin_vel_z", "orientation", "stand_still", "torques", "tracking_ang_vel", "tracking_lin_vel", "termination":
+ * the order rewards are evaluated in (class_to_dict iterates dir(), envs/helpers.py:7; termination is added last,
+ * envs/nightmare_v3_env.py:132-137, 285). The config names `collision` and `feet_stumble` (:95-96) have no function upstream. */
 const char* nm_reward_name(int i);
 const char* nm_last_error(void);
 
@@ -55,7 +63,7 @@ int32_t nm_num_envs(const nm_env* env);
 int32_t nm_dtype(const nm_env* env);
 
 /* reset_idx(env_ids) (envs/nightmare_v3_env.py:335-371). ids: HOST int32 array, NULL = all envs.
- * ep_stats_dev [8] f32 receives extras['episode'] (mean episode sums / episode_length_s);
+ * ep_stats_dev [NM_NUM_REWARDS] f32 receives extras['episode'] (mean episode sums / episode_length_s);
  * episode_length_dev [N] i64 is the caller-owned episode_length_buf (envs/nightmare_v3_env.py:88). */
 int nm_reset(nm_env* env, const int32_t* ids_host, int32_t n, int64_t* episode_length_dev, float* ep_stats_dev,
              void* stream);
@@ -64,7 +72,7 @@ int nm_reset(nm_env* env, const int32_t* ids_host, int32_t n, int64_t* episode_l
  *   actions_dev        [N,18] f32 (read only)
  *   episode_length_dev [N] i64   in/out (episode_length_buf)
  *   obs_dev [N,66] f32, rew_dev [N] f32, done_dev [N] i64: the returned tuple (:311)
- *   time_outs_dev [N] f32, ep_stats_dev [8] f32: extras; like the reference (:344-371) they are only
+ *   time_outs_dev [N] f32, ep_stats_dev [NM_NUM_REWARDS] f32: extras; like the reference (:344-371) they are only
  *   refreshed by a step in which at least one env reset. */
 int nm_step(nm_env* env, const float* actions_dev, int64_t* episode_length_dev, float* obs_dev, float* rew_dev,
             int64_t* done_dev, float* time_outs_dev, float* ep_stats_dev, void* stream);
@@ -79,10 +87,14 @@ int nm_get_state(nm_env* env, double* qpos, double* qvel, double* qacc_warmstart
 int nm_set_state(nm_env* env, const double* qpos, const double* qvel, const double* qacc_warmstart);
 /* The host-side buffers the reference keeps between steps (self.dof_pos, self.dof_vel, self.actions,
  * self.commands, self.episode_sums; envs/nightmare_v3_env.py:60-61,94-96,140). HOST doubles, NULL = skip.
- * episode_sums is [N,8] in nm_reward_name order. */
+ * episode_sums is [N,NM_NUM_REWARDS] in nm_reward_name order. */
 int nm_get_buffers(nm_env* env, double* dof_pos, double* dof_vel, double* actions, double* commands, double* episode_sums);
 int nm_set_buffers(nm_env* env, const double* dof_pos, const double* dof_vel, const double* actions,
                    const double* commands, const double* episode_sums);
+/* State of _reward_feet_air_time (self.feet_air_time, self.last_contacts, self.last_contacts_filt; envs/nightmare_v3_env.py:90-93,
+ * 447-477). HOST arrays: feet_air_time [N,6] double, last_contacts / last_contacts_filt [N,6] uint8. NULL = skip. Synchronous. */
+int nm_get_feet_state(nm_env* env, double* feet_air_time, unsigned char* last_contacts, unsigned char* last_contacts_filt);
+int nm_set_feet_state(nm_env* env, const double* feet_air_time, const unsigned char* last_contacts, const unsigned char* last_contacts_filt);
 /* RNG-free command resampling for parity tests: HOST [N,4] uniforms in [0,1) used by the next steps instead
  * of the counter RNG ((x,yaw) for the periodic resample :235, (x,yaw) for the reset resample :356). NULL = RNG. */
 int nm_set_command_uniforms(nm_env* env, const double* u_host);

@@ -5,12 +5,12 @@ import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NM_HIP_LIB") or os.path.join(HERE, "csrc", "libnightmare_hip.so")   # NM_HIP_LIB: measurement builds
-NUM_OBS, NUM_ACTIONS, NUM_REWARDS = 66, 18, 8
+NUM_OBS, NUM_ACTIONS, NUM_REWARDS = 66, 18, 16
 DTYPE_F32, DTYPE_F64 = 0, 1
 
 EXPORTS = ["nm_default_config", "nm_reward_name", "nm_last_error", "nm_create", "nm_destroy", "nm_num_envs", "nm_dtype", "nm_reset",
            "nm_step", "nm_step_physics", "nm_get_state", "nm_set_state", "nm_get_buffers", "nm_set_buffers",
-           "nm_set_command_uniforms", "nm_get_counters", "nm_set_debug_buffer", "nm_policy_forward", "nm_policy_pack", "nm_policy_forward_packed", "nm_profile", "nm_set_ablation", "nm_gae",
+           "nm_set_command_uniforms", "nm_get_feet_state", "nm_set_feet_state", "nm_get_counters", "nm_set_debug_buffer", "nm_policy_forward", "nm_policy_pack", "nm_policy_forward_packed", "nm_profile", "nm_set_ablation", "nm_gae",
            "nm_set_observation_noise", "nm_set_noise_uniforms", "nm_set_state_record", "nm_get_state_record",
            "nm_nik_create", "nm_nik_destroy", "nm_nik_reset", "nm_nik_update", "nm_nik_get_state"]
 
@@ -20,7 +20,9 @@ class NmConfig(C.Structure):
                 ("clip_actions", C.c_double), ("clip_observations", C.c_double),
                 ("obs_lin_vel", C.c_double), ("obs_ang_vel", C.c_double), ("obs_dof_pos", C.c_double), ("obs_dof_vel", C.c_double),
                 ("episode_length_s", C.c_double), ("resampling_time", C.c_double), ("max_lin_vel_x", C.c_double), ("max_ang_vel", C.c_double),
-                ("termination_contact_force", C.c_double), ("tracking_sigma", C.c_double), ("reward_scales", C.c_double * NUM_REWARDS)]
+                ("termination_contact_force", C.c_double), ("tracking_sigma", C.c_double), ("reward_scales", C.c_double * NUM_REWARDS),
+                ("tibia_contact_mode", C.c_int32), ("tibia_max_contact_force", C.c_double), ("body_contact_mode", C.c_int32),
+                ("body_max_contact_force", C.c_double), ("base_height_target", C.c_double), ("max_contact_force", C.c_double)]
 
 
 class NightmareHipError(RuntimeError):
@@ -57,6 +59,8 @@ def load():
     L.nm_get_buffers.argtypes = [vp] * 6
     L.nm_set_buffers.argtypes = [vp] * 6
     L.nm_set_command_uniforms.argtypes = [vp, vp]
+    L.nm_get_feet_state.argtypes = [vp] * 4
+    L.nm_set_feet_state.argtypes = [vp] * 4
     L.nm_get_counters.argtypes = [vp, vp]
     L.nm_set_debug_buffer.argtypes = [vp, vp]
     L.nm_profile.argtypes = [vp, C.c_int32, vp, vp]

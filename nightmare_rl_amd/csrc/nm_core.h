@@ -31,7 +31,7 @@ namespace nm {
 using namespace simt;
 
 // ----------------------------------------------------------------------------------------- layout constants
-constexpr int kNQ = 25, kNV = 24, kNU = 18, kNLEG = 6, kNCOL = 7, kNSENS = 13, kNOBS = 66, kNREW = 8;
+constexpr int kNQ = 25, kNV = 24, kNU = 18, kNLEG = 6, kNCOL = 7, kNSENS = 13, kNOBS = 66, kNREW = 16;
 constexpr int kLinkN = 25;             // per-link constants: bpos3 bR9 axis3 ipos3 Ibody6 mass1
 constexpr int kLegN = 3 * kLinkN;      // per-leg constants
 constexpr int kBaseN = 10;             // ipos3 Ibody6 mass1
@@ -39,7 +39,10 @@ constexpr int kColN = 24;              // per colliding mesh: center3 rbound inv
 constexpr int kMaxCon = 16;            // contacts kept per env (rows = 4*kMaxCon = one per lane)
 constexpr int kMaxRow = 4 * kMaxCon;
 constexpr int kJRow = 16;              // LDS row: Jb6 Jl3 leg | Jm3 leg1 (body1 side of a tibia-tibia contact) pad2
-enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
+// every reward name of the reference config that has a _reward_ function (env.py:399-497), in the order class_to_dict yields them
+// (dir() = alphabetical, helpers.py:7); termination last because step() adds it last (env.py:285-288)
+enum { R_ACTION_RATE, R_ANG_VEL_XY, R_BASE_HEIGHT, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_DOF_VEL, R_FEET_AIR_TIME, R_FEET_CONTACT,
+       R_LIN_VEL_Z, R_ORIENTATION, R_STAND_STILL, R_TORQUES, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
 
 // model + config constants, converted once to `real` by the host. The device kernel copies the struct (3 KB in fp32) into LDS
 // when a wave starts, so every M.x below is an LDS broadcast read, not a scalar load through a pointer.
@@ -63,8 +66,12 @@ template <class real> struct Model {
   real dt, p_gain, clip_obs, obs_lin, obs_ang, obs_dofpos, obs_dofvel, max_lin_x, max_ang, term_force, sigma, max_ep_len, default_pos[3];
   float action_scale, clip_actions;
   int resample_every;
-  real rew_scale[kNREW];
+  real rew_scale[kNREW];   // config scale x dt (env.py:123-128); 0 = not in the reward table, its function never runs
   real ep_len_s;
+  // terms the reference config ships with scale 0 (config.py:88-95) and contact modes other than 1 (config.py:17-21)
+  int rew_extra;           // any of ang_vel_xy base_height dof_vel feet_air_time feet_contact_forces lin_vel_z stand_still is in the table
+  int tibia_mode, body_mode;
+  real tibia_max, body_max, base_h_target, max_contact_force;
 };
 
 // per-launch arguments (device pointers, AoS-by-env rows so one wave reads contiguous bytes)
@@ -76,6 +83,8 @@ template <class real> struct Args {
   real *qpos, *qvel, *qwarm;
   // env buffers the reference keeps between steps
   real *dofpos, *dofvel, *act, *cmd, *epsum;
+  real* feetair;         // [N,6] feet_air_time (env.py:90); touched only while feet_air_time is in the reward table
+  int* feetflags;        // [N] bits 0..5 last_contacts, bits 6..11 last_contacts_filt (env.py:92-93)
   int64_t* eplen;
   uint32_t* rngctr;
   int* hullcache;        // [N,8] warm start of the support-vertex search (any value in range is valid)
@@ -86,7 +95,11 @@ template <class real> struct Args {
   float *obs, *rew, *timeout_now;
   int64_t* done;
   real* stat_sum;        // [kNREW] sums of episode sums over envs that reset this step
-  int* stat_cnt;         // [4]: #resets this step, #contacts dropped (contact cap), #bad-state resets (mj_check*)
+  int* stat_cnt;         // [4]: #resets this step, #contacts dropped (contact cap), #bad-state resets (mj_check*), #hull-search fallbacks
+  // end of step, done by whichever wave finishes last (device build): extras refreshed only when >= 1 env reset (env.py:344-371)
+  int* wave_done;        // [1] waves that have published their results in this launch
+  float *ep_stats, *time_outs;   // [kNREW] extras['episode'], [N] extras['time_outs']
+  long long* counters;   // [3] running totals of stat_cnt[1..3]
   real* dbg;             // optional [N][kDbgN]
   int nsub;              // decimation
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
@@ -114,6 +127,7 @@ template <class real> struct Sh {
   real cpos[kMaxCon * 3], cdist[kMaxCon], cnrm[kMaxCon * 3];
   int cleg[kMaxCon], cleg1[kMaxCon];   // leg of body2 (-1 = base), leg of body1 (-1 = world/floor)
   real sens[16], cvb[6];
+  real bh[2];                     // xipos[1][2] of the last forward pass (env.py:223)
   real mbb[36], sc[36];           // base block of M and its Schur complement (upper triangles)
   real legtmp[kNLEG * 66];        // per-leg staging between the forward and backward chain passes: 3 x (S6 I10 f6)
   real efc_f[kMaxRow];
@@ -123,7 +137,7 @@ template <class real> struct Sh {
   int ncon, nwarn, it_pgs, it_noslip, anypair;
   int nfallback, nhop;
   real eact[kNU], epact[kNU], epdv[kNU];  // this step's clipped actions, last step's actions and joint velocities (epilogue inputs)
-  real ecmd[4], eepsum[8];        // env buffers fetched at load time for the epilogue: commands, episode sums
+  real ecmd[4], eepsum[kNREW];    // env buffers fetched at load time for the epilogue: commands, episode sums
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
   unsigned ectr;                  // command RNG counter
   int cstart[8], ccnt[8];         // contacts of colliding mesh g (0 = base, 1..6 = tibias): first index and count (floor contacts)
@@ -502,6 +516,7 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
       cross3(t, vb, cr);
 #pragma unroll
       for (int j = 0; j < 3; j++) { STG(cvb, j, vb[j]); STG(cvb, 3 + j, vb[3 + j] + t[j]); }
+      STG(bh, 0, LDG(qpos, 2) + d[2]);   // z of the base body's COM
     }
     vr fb[6], t6[6], u6[6], w6[6];
     inert_mul(t6, Ib10, ab);
@@ -1848,6 +1863,13 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #pragma unroll
     for (int l = 1; l < 6; l++) fm = vmax(fm, feet[l]);
     reset = reset | (fm > M.term_force);
+    if ((M.tibia_mode == 2) | (M.body_mode == 2)) {   // env.py:248-251: terminate on tibia / body contact (off in the default config)
+      real tm = tib[0];
+#pragma unroll
+      for (int l = 1; l < 6; l++) tm = vmax(tm, tib[l]);
+      if (M.tibia_mode == 2) reset = reset | (tm > M.tibia_max);
+      if (M.body_mode == 2) reset = reset | (body > M.body_max);
+    }
     real nrm = vsqrt(pg[0] * pg[0] + pg[1] * pg[1] + pg[2] * pg[2]);
     // angle(projected gravity, straight down) > 60 deg. The fp32 build compares cosines instead of calling acosf (equivalent
     // except within an ulp of the threshold); the fp64 verification build keeps the reference's expression.
@@ -1876,10 +1898,16 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
   nm_stamp(13);
   // ---- E7 (env.py:277-288, 399-497): rewards (alphabetical, termination last)
   real rt[kNREW];
+#pragma unroll
+  for (int k = 0; k < kNREW; k++) rt[k] = real(0);
   {
     vr da = prev_act - act;
     rt[R_ACTION_RATE] = wsum<real>(sel(l18, da * da, vr(real(0)))) * M.rew_scale[R_ACTION_RATE];
     real sumt = ((tib[0] + tib[1]) + (tib[2] + tib[3])) + (tib[4] + tib[5]);
+    if ((M.tibia_mode != 1) | (M.body_mode != 1)) {   // env.py:479-485: each part counts only in mode 1
+      sumt = M.tibia_mode == 1 ? sumt : real(0);
+      body = M.body_mode == 1 ? body : real(0);
+    }
     rt[R_BODY_CONTACT] = (sumt + body) * M.rew_scale[R_BODY_CONTACT];
     vr dp = dofpos - defp;
     rt[R_DEFAULT_POS] = wsum<real>(sel(l18, dp * dp, vr(real(0)))) * M.rew_scale[R_DEFAULT_POS];
@@ -1891,6 +1919,40 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     real el = (cmd[0] - blv[0]) * (cmd[0] - blv[0]) + (cmd[1] - blv[1]) * (cmd[1] - blv[1]);
     rt[R_TRACK_LIN] = vexp(-el / M.sigma) * M.rew_scale[R_TRACK_LIN];
     rt[R_TERMINATION] = (reset && !time_out) ? M.rew_scale[R_TERMINATION] : real(0);
+    // rt[R_TORQUES] stays 0: env.py:415-417 squares qfrc_applied[-18:] (env.py:222), which nothing ever writes
+    if (M.rew_extra) {   // the terms config.py:88-95 ships with scale 0: one uniform branch in the default configuration
+      rt[R_ANG_VEL_XY] = (bav[0] * bav[0] + bav[1] * bav[1]) * M.rew_scale[R_ANG_VEL_XY];                  // env.py:403-405
+      real dh = sh.bh[0] - M.base_h_target;
+      rt[R_BASE_HEIGHT] = dh * dh * M.rew_scale[R_BASE_HEIGHT];                                            // env.py:411-413
+      rt[R_DOF_VEL] = wsum<real>(sel(l18, dofvel * dofvel, vr(real(0)))) * M.rew_scale[R_DOF_VEL];           // env.py:419-421
+      rt[R_LIN_VEL_Z] = blv[2] * blv[2] * M.rew_scale[R_LIN_VEL_Z];                                        // env.py:399-401
+      real still = vsqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1]) < real(0.01) ? real(1) : real(0);
+      rt[R_STAND_STILL] = wsum<real>(sel(l18, vabs(dp), vr(real(0)))) * still * M.rew_scale[R_STAND_STILL];  // env.py:487-489
+      const VB l6 = lane < kNLEG;
+      const V<int> l6c = sel(l6, lane, V<int>(0));
+      const vr ff = ldsv(sh.sens, l6c + 6);
+      vr over = sel(ff > vr(M.max_contact_force), ff - M.max_contact_force, vr(real(0)));
+      rt[R_FEET_CONTACT] = wsum<real>(sel(l6, over * over, vr(real(0)))) * M.rew_scale[R_FEET_CONTACT];      // env.py:491-493
+      if (M.rew_scale[R_FEET_AIR_TIME] != real(0)) {   // env.py:458-477; stateful: runs only while it is in the reward table
+        vr air = gldv(A.feetair, l6c + env * kNLEG);
+        const V<int> fl = V<int>(gld1(A.feetflags, env));
+        if (reset) air = vr(real(0));                  // reset_idx zeroes feet_air_time (env.py:359) before the rewards run
+        const VB contact = ff > vr(real(1));
+        const VB filt = contact | (((fl >> l6c) & 1) != 0);
+        const VB lastf = ((fl >> (l6c + kNLEG)) & 1) != 0;
+        air = air + M.dt;
+        air = sel(filt == lastf, air, vr(real(0)));    // reset air time if the filtered contact changes
+        const vr single = sel(air > vr(real(1)), air - real(1), vr(real(0))) + sel(air < vr(real(0.5)), real(0.5) - air, vr(real(0)));
+        rt[R_FEET_AIR_TIME] = wsum<real>(sel(l6, single * single, vr(real(0)))) * M.rew_scale[R_FEET_AIR_TIME];
+        gstv(A.feetair, l6c + env * kNLEG, air, l6);
+        const int nf = (int)(ballot(l6 & contact) | (ballot(l6 & filt) << kNLEG));
+#ifdef NM_EMUL
+        A.feetflags[env] = nf;
+#else
+        if (threadIdx.x == 0) gst1(A.feetflags, env, nf);
+#endif
+      }
+    }
   }
   real rew = real(0);
 #pragma unroll

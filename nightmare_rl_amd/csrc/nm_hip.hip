@@ -25,6 +25,37 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 #ifndef NM_ENVS_PER_WAVE
 #define NM_ENVS_PER_WAVE 2
 #endif
+// extras: like the reference, 'episode' and 'time_outs' are refreshed only by a step in which >= 1 env reset (env.py:344-371);
+// then the per-step accumulators are cleared for the next launch. One wave, after all others have published.
+template <class real> __device__ __noinline__ void step_tail(const nm::Args<real>& A, real ep_len_s) {
+  const int lane = threadIdx.x;
+  const int cnt = __hip_atomic_load(A.stat_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (cnt > 0) {
+    if (lane < nm::kNREW && A.ep_stats) {
+      const real s = __hip_atomic_load(A.stat_sum + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      A.ep_stats[lane] = (float)(s / (real)cnt / ep_len_s);
+    }
+    if (A.time_outs) {   // [N] floats: 16 independent loads per lane in flight, then the stores
+      constexpr int kU = 16;
+      for (int base = 0; base < A.N; base += 64 * kU) {
+        float v[kU];
+#pragma unroll
+        for (int u = 0; u < kU; u++) { const int i = base + u * 64 + lane; v[u] = i < A.N ? A.timeout_now[i] : 0.f; }
+#pragma unroll
+        for (int u = 0; u < kU; u++) { const int i = base + u * 64 + lane; if (i < A.N) A.time_outs[i] = v[u]; }
+      }
+    }
+  }
+  if (lane < nm::kNREW) A.stat_sum[lane] = real(0);
+  if (lane == 0) {
+    A.counters[0] += __hip_atomic_load(A.stat_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    A.counters[1] += __hip_atomic_load(A.stat_cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    A.counters[2] += __hip_atomic_load(A.stat_cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    A.stat_cnt[0] = 0; A.stat_cnt[1] = 0; A.stat_cnt[2] = 0; A.stat_cnt[3] = 0;
+    *A.wave_done = 0;
+  }
+}
+
 template <class real, int G>
 __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
   __shared__ nm::ShW<real, G> sh;
@@ -40,6 +71,16 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
     __syncthreads();
   }
   nm::wave_step<real, G>(sh, Ms, As, wave);
+  if (As.physics_only) return;
+  // The wave that finishes last closes the step (what used to be a second launch): every wave publishes its results
+  // (release fence), takes a ticket, and the holder of the last ticket sees all of them (acquire fence).
+  __threadfence();
+  int ticket = 0;
+  if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done, 1);
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != (int)gridDim.x - 1) return;
+  __threadfence();
+  step_tail<real>(As, Ms.ep_len_s);
 }
 
 // reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
@@ -63,6 +104,7 @@ __global__ void k_reset(nm::Model<real> M, nm::Args<real> A, const int32_t* ids,
   A.cmd[env * 3] = c0 * keep; A.cmd[env * 3 + 1] = real(0); A.cmd[env * 3 + 2] = c2;
   A.rngctr[env] = ctr;
   A.eplen[env] = 0;
+  for (int k = 0; k < nm::kNLEG; k++) A.feetair[env * nm::kNLEG + k] = real(0);   // env.py:359 (last_contacts* are not cleared)
   for (int k = 0; k < nm::kNREW; k++) {
     atomicAdd(A.stat_sum + k, A.epsum[env * nm::kNREW + k]);
     A.epsum[env * nm::kNREW + k] = real(0);
@@ -70,8 +112,7 @@ __global__ void k_reset(nm::Model<real> M, nm::Args<real> A, const int32_t* ids,
   atomicAdd(A.stat_cnt, 1);
 }
 
-// extras: like the reference, 'episode' and 'time_outs' are refreshed only when >= 1 env reset (env.py:344-371).
-// Single workgroup, so it can clear the accumulators after everyone has read them.
+// the same closing step as a kernel of its own, for reset_idx() (k_reset fills the accumulators, nothing else is in flight)
 template <class real>
 __global__ void k_finalize(int N, real* stat_sum, int* stat_cnt, float* ep_stats, const float* timeout_now, float* time_outs,
                            real ep_len_s, long long* counters) {
@@ -108,6 +149,8 @@ struct nm_env {
   virtual int get_buffers(double* dp, double* dv, double* act, double* cmd, double* es) = 0;
   virtual int set_buffers(const double* dp, const double* dv, const double* act, const double* cmd, const double* es) = 0;
   virtual int set_cmd_u(const double* u) = 0;
+  virtual int get_feet(double* air, unsigned char* last, unsigned char* filt) = 0;
+  virtual int set_feet(const double* air, const unsigned char* last, const unsigned char* filt) = 0;
   virtual int counters(int64_t* out) = 0;
   virtual void set_dbg(void* p) = 0;
   virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
@@ -163,9 +206,9 @@ template <class real> struct Env : nm_env {
     A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
     size_t n_ = (size_t)N;
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
-        dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * 8) ||
-        dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, 8) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
-        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4))
+        dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * nm::kNREW) || dalloc(&A.feetair, n_ * nm::kNLEG) || dalloc(&A.feetflags, n_) ||
+        dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, nm::kNREW) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, 1))
       return 1;
     if (dalloc(&M_dev, 1)) return 1;
     HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));
@@ -196,6 +239,7 @@ template <class real> struct Env : nm_env {
       for (int i = 0; i < n; i++)
         if (ids[i] < 0 || ids[i] >= N) return fail("nm_reset: env id out of range");
       HIPCHK(hipMemcpyAsync(ids_dev, ids, sizeof(int32_t) * n, hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));   // the caller's host array may go away as soon as we return
       idp = ids_dev;
     } else n = N;
     nm::Args<real> a = A;
@@ -214,6 +258,7 @@ template <class real> struct Env : nm_env {
     a.actions = actions; a.eplen = eplen; a.obs = obs; a.rew = rew; a.done = done; a.timeout_now = timeout_now;
     a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
     a.physics_only = physics_only;
+    a.ep_stats = ep_stats; a.time_outs = time_outs; a.counters = counters_dev;
     if (!physics_only) {
       a.noise_vec = noise_on ? noise_vec_dev : nullptr;
       a.noise_u = noise_on && noise_u_on ? noise_u_dev : nullptr;
@@ -236,8 +281,7 @@ template <class real> struct Env : nm_env {
     hipLaunchKernelGGL((k_env_step<real, G>), dim3((N + G - 1) / G), dim3(64), 0, s, (const nm::Model<real>*)M_dev, a);
     HIPCHK(hipGetLastError());
     if (prof_on) HIPCHK(hipEventRecord(e1, s));
-    if (physics_only) return 0;
-    return finalize(ep_stats, time_outs, s);
+    return 0;
   }
   int d2h(const real* dev, double* host, size_t n) {
     if (!host) return 0;
@@ -267,13 +311,42 @@ template <class real> struct Env : nm_env {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipDeviceSynchronize());
     return d2h(A.dofpos, dp, (size_t)N * 18) || d2h(A.dofvel, dv, (size_t)N * 18) || d2h(A.act, act, (size_t)N * 18) ||
-           d2h(A.cmd, cmd, (size_t)N * 3) || d2h(A.epsum, es, (size_t)N * 8);
+           d2h(A.cmd, cmd, (size_t)N * 3) || d2h(A.epsum, es, (size_t)N * nm::kNREW);
   }
   int set_buffers(const double* dp, const double* dv, const double* act, const double* cmd, const double* es) override {
     HIPCHK(hipSetDevice(device));
     HIPCHK(hipDeviceSynchronize());
     return h2d(A.dofpos, dp, (size_t)N * 18) || h2d(A.dofvel, dv, (size_t)N * 18) || h2d(A.act, act, (size_t)N * 18) ||
-           h2d(A.cmd, cmd, (size_t)N * 3) || h2d(A.epsum, es, (size_t)N * 8);
+           h2d(A.cmd, cmd, (size_t)N * 3) || h2d(A.epsum, es, (size_t)N * nm::kNREW);
+  }
+  int get_feet(double* air, unsigned char* last, unsigned char* filt) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    if (d2h(A.feetair, air, (size_t)N * 6)) return 1;
+    std::vector<int> fl(N);
+    HIPCHK(hipMemcpy(fl.data(), A.feetflags, sizeof(int) * N, hipMemcpyDeviceToHost));
+    for (int i = 0; i < N; i++)
+      for (int k = 0; k < 6; k++) {
+        if (last) last[i * 6 + k] = (fl[i] >> k) & 1;
+        if (filt) filt[i * 6 + k] = (fl[i] >> (6 + k)) & 1;
+      }
+    return 0;
+  }
+  int set_feet(const double* air, const unsigned char* last, const unsigned char* filt) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipDeviceSynchronize());
+    if (h2d(A.feetair, air, (size_t)N * 6)) return 1;
+    if (last || filt) {
+      std::vector<int> fl(N);
+      HIPCHK(hipMemcpy(fl.data(), A.feetflags, sizeof(int) * N, hipMemcpyDeviceToHost));
+      for (int i = 0; i < N; i++)
+        for (int k = 0; k < 6; k++) {
+          if (last) fl[i] = (fl[i] & ~(1 << k)) | ((last[i * 6 + k] ? 1 : 0) << k);
+          if (filt) fl[i] = (fl[i] & ~(1 << (6 + k))) | ((filt[i * 6 + k] ? 1 : 0) << (6 + k));
+        }
+      HIPCHK(hipMemcpy(A.feetflags, fl.data(), sizeof(int) * N, hipMemcpyHostToDevice));
+    }
+    return 0;
   }
   int set_cmd_u(const double* u) override {
     HIPCHK(hipSetDevice(device));
@@ -342,8 +415,10 @@ template <class real> struct Env : nm_env {
 };
 
 // ------------------------------------------------------------------------------------------------ C ABI
-static const char* kRewardNames[NM_NUM_REWARDS] = {"action_rate", "body_contact_forces", "default_position", "dof_acc",
-                                                   "orientation", "tracking_ang_vel", "tracking_lin_vel", "termination"};
+static const char* kRewardNames[NM_NUM_REWARDS] = {"action_rate", "ang_vel_xy", "base_height", "body_contact_forces", "default_position", "dof_acc",
+                                                   "dof_vel", "feet_air_time", "feet_contact_forces", "lin_vel_z", "orientation", "stand_still",
+                                                   "torques", "tracking_ang_vel", "tracking_lin_vel", "termination"};
+static_assert(NM_NUM_REWARDS == nm::kNREW, "reward table size");
 extern "C" {
 const char* nm_last_error(void) { return g_err.c_str(); }
 int nm_policy_set_error(const char* m) { return fail(m); }
@@ -358,6 +433,9 @@ void nm_default_config(nm_config* c) {
   c->max_lin_vel_x = d.max_lin_vel_x; c->max_ang_vel = d.max_ang_vel;
   c->termination_contact_force = d.termination_contact_force; c->tracking_sigma = d.tracking_sigma;
   for (int i = 0; i < NM_NUM_REWARDS; i++) c->reward_scales[i] = d.rew_scales[i];
+  c->tibia_contact_mode = d.tibia_contact_mode; c->tibia_max_contact_force = d.tibia_max_contact_force;
+  c->body_contact_mode = d.body_contact_mode; c->body_max_contact_force = d.body_max_contact_force;
+  c->base_height_target = d.base_height_target; c->max_contact_force = d.max_contact_force;
 }
 int nm_create(const nm_config* cfg, int32_t num_envs, int32_t device, uint64_t seed, int64_t env_id_offset, int32_t dtype, nm_env** out) {
   if (!out) return fail("nm_create: out is NULL");
@@ -370,6 +448,11 @@ int nm_create(const nm_config* cfg, int32_t num_envs, int32_t device, uint64_t s
   nmhost::EnvConfig c;
   if (cfg) {
     if (cfg->decimation < 1) return fail("nm_create: decimation must be >= 1");
+    if (!(cfg->episode_length_s > 0)) return fail("nm_create: episode_length_s must be positive");
+    // env.py:235 takes episode_length % int(resampling_time / dt): a period below one step is a division by zero upstream
+    if ((int)(cfg->resampling_time / (NM_TIMESTEP * cfg->decimation)) < 1) return fail("nm_create: resampling_time must be at least one env step (dt)");
+    if (cfg->tibia_contact_mode < 0 || cfg->tibia_contact_mode > 2 || cfg->body_contact_mode < 0 || cfg->body_contact_mode > 2)
+      return fail("nm_create: contact modes are 0 (ignore), 1 (penalise) or 2 (terminate)");
     c.decimation = cfg->decimation; c.p_gain = cfg->p_gain; c.action_scale = cfg->action_scale;
     for (int i = 0; i < 3; i++) c.default_pos[i] = cfg->default_pos[i];
     c.clip_actions = cfg->clip_actions; c.clip_observations = cfg->clip_observations;
@@ -378,6 +461,9 @@ int nm_create(const nm_config* cfg, int32_t num_envs, int32_t device, uint64_t s
     c.max_lin_vel_x = cfg->max_lin_vel_x; c.max_ang_vel = cfg->max_ang_vel;
     c.termination_contact_force = cfg->termination_contact_force; c.tracking_sigma = cfg->tracking_sigma;
     for (int i = 0; i < NM_NUM_REWARDS; i++) c.rew_scales[i] = cfg->reward_scales[i];
+    c.tibia_contact_mode = cfg->tibia_contact_mode; c.tibia_max_contact_force = cfg->tibia_max_contact_force;
+    c.body_contact_mode = cfg->body_contact_mode; c.body_max_contact_force = cfg->body_max_contact_force;
+    c.base_height_target = cfg->base_height_target; c.max_contact_force = cfg->max_contact_force;
   }
   nm_env* e;
   int rc;
@@ -408,6 +494,8 @@ int nm_get_buffers(nm_env* env, double* dp, double* dv, double* act, double* cmd
 int nm_set_buffers(nm_env* env, const double* dp, const double* dv, const double* act, const double* cmd, const double* es) {
   NEED(env); return env->set_buffers(dp, dv, act, cmd, es);
 }
+int nm_get_feet_state(nm_env* env, double* air, unsigned char* last, unsigned char* filt) { NEED(env); return env->get_feet(air, last, filt); }
+int nm_set_feet_state(nm_env* env, const double* air, const unsigned char* last, const unsigned char* filt) { NEED(env); return env->set_feet(air, last, filt); }
 int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_cmd_u(u); }
 int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }

@@ -25,8 +25,11 @@ struct EnvConfig {
   double max_lin_vel_x = 0.5, max_ang_vel = 0.8;  // :62,:64
   double termination_contact_force = 160.0;       // :22
   double tracking_sigma = 0.008;    // :98
-  // reward scales (:78-86), order = nm::R_* (alphabetical, termination last)
-  double rew_scales[nm::kNREW] = {-0.02, -5.0, -0.01, -2.5e-5, -5.0, 6.0, 8.0, -200.0};
+  // reward scales (:78-95), order = nm::R_* (alphabetical, termination last); the reference ships eight of them as 0
+  double rew_scales[nm::kNREW] = {-0.02, 0, 0, -5.0, -0.01, -2.5e-5, 0, 0, 0, 0, -5.0, 0, 0, 6.0, 8.0, -200.0};
+  int tibia_contact_mode = 1, body_contact_mode = 1;                    // :18,:20
+  double tibia_max_contact_force = 2.0, body_max_contact_force = 2.0;   // :19,:21
+  double base_height_target = 0.1, max_contact_force = 10.0;            // :99,:100
 };
 
 inline void quat2mat(const double* q, double* m) {
@@ -147,6 +150,12 @@ template <class real> struct Tables {
     M.resample_every = (int)(cfg.resampling_time / dt);             // env.py:235
     for (int k = 0; k < nm::kNREW; k++) M.rew_scale[k] = (real)(cfg.rew_scales[k] * dt);  // env.py:123-128
     M.ep_len_s = (real)cfg.episode_length_s;
+    M.rew_extra = 0;
+    for (int k : {nm::R_ANG_VEL_XY, nm::R_BASE_HEIGHT, nm::R_DOF_VEL, nm::R_FEET_AIR_TIME, nm::R_FEET_CONTACT, nm::R_LIN_VEL_Z, nm::R_STAND_STILL})
+      if (cfg.rew_scales[k] != 0) M.rew_extra = 1;
+    M.tibia_mode = cfg.tibia_contact_mode; M.body_mode = cfg.body_contact_mode;
+    M.tibia_max = (real)cfg.tibia_max_contact_force; M.body_max = (real)cfg.body_max_contact_force;
+    M.base_h_target = (real)cfg.base_height_target; M.max_contact_force = (real)cfg.max_contact_force;
   }
 };
 

@@ -38,8 +38,8 @@ class NightmareV3Env:
             raise ValueError("the compiled path is specialised for num_obs=66, num_actions=18")
         if cfg.viewer.render:
             raise ValueError("cfg.viewer.render is not available on the GPU path (set it to False)")
-        if cfg.env.tibia_contact_mode != 1 or cfg.env.body_contact_mode != 1:
-            raise NotImplementedError("only tibia/body_contact_mode == 1 (the reference default) is compiled")
+        if cfg.env.tibia_contact_mode not in (0, 1, 2) or cfg.env.body_contact_mode not in (0, 1, 2):
+            raise ValueError("tibia/body_contact_mode: 0 do nothing, 1 penalize on contact, 2 terminate on contact")
         if not torch.cuda.is_available():
             raise _lib.NightmareHipError("NightmareV3Env needs a HIP device: there is no CPU path")
         L = _lib.load()
@@ -58,14 +58,17 @@ class NightmareV3Env:
         self.max_episode_length_s = cfg.env.episode_length_s
         self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
         self.default_dof_pos = np.array(cfg.control.default_pos, dtype=np.float64)
-        # reward table: zero scales dropped, the rest x dt (reference :123-128); names with no compiled function are rejected
+        if int(cfg.commands.resampling_time / self.dt) < 1:
+            raise ValueError("cfg.commands.resampling_time must be at least one env step (reference :235 takes a modulo by it)")
+        # reward table: zero scales dropped, the rest x dt (reference :123-128). Every name the reference has a _reward_ function
+        # for (:399-497) is compiled; a name without one (`collision`, `feet_stumble`, config :95-96) fails like upstream's getattr.
         names = _lib.reward_names()
         for key in list(self.reward_scales.keys()):
             if self.reward_scales[key] == 0:
                 self.reward_scales.pop(key)
             else:
                 if key not in names:
-                    raise NotImplementedError(f"reward '{key}' has a non-zero scale but is not on the compiled path ({names})")
+                    raise AttributeError(f"'NightmareV3Env' object has no attribute '_reward_{key}'")
                 self.reward_scales[key] *= self.dt
         self.reward_names = [n for n in self.reward_scales if n != "termination"]
         dp = list(cfg.control.default_pos)
@@ -90,6 +93,9 @@ class NightmareV3Env:
         raw = class_to_dict(cfg.rewards.scales)
         for i, n in enumerate(names):
             c.reward_scales[i] = float(raw.get(n, 0.0))
+        c.tibia_contact_mode, c.tibia_max_contact_force = int(cfg.env.tibia_contact_mode), float(cfg.env.tibia_max_contact_force)
+        c.body_contact_mode, c.body_max_contact_force = int(cfg.env.body_contact_mode), float(cfg.env.body_max_contact_force)
+        c.base_height_target, c.max_contact_force = float(cfg.rewards.base_height_target), float(cfg.rewards.max_contact_force)
         self._dtype = _lib.DTYPE_F64 if dtype == torch.float64 else _lib.DTYPE_F32
         h = C.c_void_p()
         _lib.check(L.nm_create(C.byref(c), self.num_envs, self.device.index or 0, int(seed), int(env_id_offset), self._dtype, C.byref(h)))
@@ -165,7 +171,8 @@ class NightmareV3Env:
 
     def _fill_extras(self):
         # reference :363-371: one 0-d float32 tensor per reward + time_outs; views of buffers the kernel refreshes
-        self.extras["episode"] = {"rew_" + n: self._ep_stats[i] for i, n in enumerate(self._stat_names)}
+        # keys = the reward table (non-zero scales), in its order - what upstream's episode_sums holds (:140, :363-367)
+        self.extras["episode"] = {"rew_" + n: self._ep_stats[self._stat_names.index(n)] for n in self.reward_scales}
         if self.cfg.env.send_timeouts:
             self.extras["time_outs"] = self.time_out_buf
 
@@ -243,13 +250,25 @@ class NightmareV3Env:
     def get_buffers(self):
         N = self.num_envs
         out = dict(dof_pos=np.empty((N, 18)), dof_vel=np.empty((N, 18)), actions=np.empty((N, 18)), commands=np.empty((N, 3)),
-                   episode_sums=np.empty((N, 8)))
+                   episode_sums=np.empty((N, _lib.NUM_REWARDS)))
         _lib.check(self._L.nm_get_buffers(self._h, *[out[k].ctypes.data for k in ("dof_pos", "dof_vel", "actions", "commands", "episode_sums")]))
         return out
 
     def set_buffers(self, dof_pos=None, dof_vel=None, actions=None, commands=None, episode_sums=None):
         arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (dof_pos, dof_vel, actions, commands, episode_sums)]
         _lib.check(self._L.nm_set_buffers(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+
+    def get_feet_state(self):
+        """(feet_air_time [N,6] f64, last_contacts [N,6] u8, last_contacts_filt [N,6] u8): state of _reward_feet_air_time (:90-93)."""
+        N = self.num_envs
+        air, last, filt = np.empty((N, 6)), np.empty((N, 6), np.uint8), np.empty((N, 6), np.uint8)
+        _lib.check(self._L.nm_get_feet_state(self._h, air.ctypes.data, last.ctypes.data, filt.ctypes.data))
+        return air, last, filt
+
+    def set_feet_state(self, air=None, last=None, filt=None):
+        f = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
+        arrs = [f(air, np.float64), f(last, np.uint8), f(filt, np.uint8)]
+        _lib.check(self._L.nm_set_feet_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
     def set_command_uniforms(self, u):
         a = None if u is None else np.ascontiguousarray(u, np.float64).reshape(self.num_envs, 4)

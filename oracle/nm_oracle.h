@@ -69,7 +69,10 @@ void nmo_set_collide_self(int on);                        /* tibia-tibia pairs (
 
 /* ---- env layer: NightmareV3Env restated (reference envs/nightmare_v3_env.py) ---- */
 typedef struct nmo_env nmo_env;
-#define NMO_NREW 8 /* action_rate body_contact_forces default_position dof_acc orientation tracking_ang_vel tracking_lin_vel termination */
+/* every reward name of the reference config that has a _reward_ function (env.py:399-497), alphabetical, termination last:
+ * action_rate ang_vel_xy base_height body_contact_forces default_position dof_acc dof_vel feet_air_time feet_contact_forces lin_vel_z
+ * orientation stand_still torques tracking_ang_vel tracking_lin_vel termination */
+#define NMO_NREW 16
 
 nmo_env* nmo_env_create(int num_envs, uint64_t seed, int64_t env_id_offset, int num_threads);
 void nmo_env_destroy(nmo_env* e);
@@ -79,6 +82,13 @@ void nmo_env_reset_idx(nmo_env* e, const int32_t* ids, int n, const double* cmd_
  * resample, (x,yaw) for the reset resample; NULL -> internal counter RNG. Outputs may be NULL. */
 void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done,
                   float* time_outs, double* obs64, double* rew64);
+/* non-default reward table / contact modes (config.py:17-21, 77-100). reward_scales[NMO_NREW] are the RAW config scales (x dt is
+ * applied here, env.py:123-128; 0 drops the term); NULL keeps the current ones */
+void nmo_env_configure(nmo_env* e, const double* reward_scales, int tibia_mode, double tibia_max_force, int body_mode, double body_max_force,
+                       double base_height_target, double max_contact_force);
+/* state of _reward_feet_air_time: feet_air_time[N,6], last_contacts[N,6], last_contacts_filt[N,6] (env.py:90-93) */
+void nmo_env_get_feet_state(nmo_env* e, double* air6, uint8_t* last6, uint8_t* filt6);
+void nmo_env_set_feet_state(nmo_env* e, const double* air6, const uint8_t* last6, const uint8_t* filt6);
 /* observation noise: noise_scale_vec66 NULL = off; u = injected [N,66] uniforms for the next steps or NULL = counter RNG
  * keyed (seed + NMO_NOISE_KEY, global env id, step*66 + k) */
 #define NMO_NOISE_KEY 0x4E4F495345ull
@@ -92,10 +102,10 @@ void nmo_env_get_buffers(nmo_env* e, double* dof_pos, double* dof_vel, double* a
 void nmo_env_set_buffers(nmo_env* e, const double* dof_pos, const double* dof_vel, const double* actions,
                          const double* commands, const int64_t* ep_len, const double* episode_sums);
 /* extras['episode'] of the last step in which >=1 env reset: mean episode sum / 20 per reward; returns #resets of last step */
-int nmo_env_episode_stats(nmo_env* e, double* out8);
+int nmo_env_episode_stats(nmo_env* e, double* out /* [NMO_NREW] */);
 nmo_data* nmo_env_data(nmo_env* e, int i);
 /* intermediate per-env buffers of the last step, for golden comparison (each may be NULL):
- * base_lin_vel[N,3] base_ang_vel[N,3] projected_gravity[N,3] tibia[N,6] feet[N,6] body[N] rew_terms[8,N] */
+ * base_lin_vel[N,3] base_ang_vel[N,3] projected_gravity[N,3] tibia[N,6] feet[N,6] body[N] rew_terms[NMO_NREW,N] */
 void nmo_env_get_debug(nmo_env* e, double* blv, double* bav, double* pg, double* tibia, double* feet, double* body,
                        double* rew_terms);
 /* counter-based uniform in [0,1) with 24 random bits (exact in fp32): shared definition with the HIP path */

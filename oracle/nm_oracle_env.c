@@ -32,7 +32,10 @@
 #define RESAMPLING_TIME 10.0    /* :60 */
 static const double kPi = 3.14159265358979323846;
 
-enum { R_ACTION_RATE, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_ORIENTATION, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
+/* every config name with a _reward_ function behind it (env.py:399-497), in the order class_to_dict yields them (dir() =
+ * alphabetical, helpers.py:7), termination last because step() adds it last (env.py:285-288) */
+enum { R_ACTION_RATE, R_ANG_VEL_XY, R_BASE_HEIGHT, R_BODY_CONTACT, R_DEFAULT_POS, R_DOF_ACC, R_DOF_VEL, R_FEET_AIR_TIME, R_FEET_CONTACT,
+       R_LIN_VEL_Z, R_ORIENTATION, R_STAND_STILL, R_TORQUES, R_TRACK_ANG, R_TRACK_LIN, R_TERMINATION };
 
 struct nmo_env {
   int N, nthreads;
@@ -40,7 +43,14 @@ struct nmo_env {
   int64_t env_off;
   double dt, max_episode_length;
   int resample_every;
-  double scale[NMO_NREW]; /* reward scale * dt (env.py:123-128) */
+  double scale[NMO_NREW]; /* reward scale * dt (env.py:123-128); 0 = dropped from the reward table, its function never runs */
+  /* config.py:17-21 contact modes (0 ignore, 1 penalise, 2 terminate), :99-100 reward parameters */
+  int tibia_mode, body_mode;
+  double tibia_max_force, body_max_force, base_height_target, max_contact_force;
+  /* state of _reward_feet_air_time (env.py:90-93, 447-477) */
+  double* feet_air_time;
+  uint8_t *last_contacts, *last_contacts_filt;
+  double* base_height; /* xipos[1][2] of the last forward pass (env.py:223) */
   nmo_data* data;
   nmo_scratch* scratch; /* per thread */
   double *dof_pos, *dof_vel, *commands, *episode_sums;
@@ -83,6 +93,8 @@ nmo_env* nmo_env_create(int N, uint64_t seed, int64_t env_off, int nthreads) {
   e->scale[R_TRACK_ANG] = 6.0 * e->dt;
   e->scale[R_TRACK_LIN] = 8.0 * e->dt;
   e->scale[R_TERMINATION] = -200.0 * e->dt;
+  e->tibia_mode = 1; e->body_mode = 1; e->tibia_max_force = 2.0; e->body_max_force = 2.0; /* config.py:18-21 */
+  e->base_height_target = 0.1; e->max_contact_force = 10.0;                                 /* config.py:99-100 */
   e->data = (nmo_data*)calloc(N, sizeof(nmo_data));
   e->scratch = (nmo_scratch*)calloc(e->nthreads, sizeof(nmo_scratch));
   for (int i = 0; i < N; i++) nmo_reset_data(&e->data[i]);
@@ -93,6 +105,7 @@ nmo_env* nmo_env_create(int N, uint64_t seed, int64_t env_off, int nthreads) {
   AL(blv, double, N * 3); AL(bav, double, N * 3); AL(pg, double, N * 3); AL(tibia, double, N * 6);
   AL(feet, double, N * 6); AL(body, double, N); AL(rew_terms, double, NMO_NREW * N);
   AL(reset_buf, int64_t, N); AL(time_out, uint8_t, N);
+  AL(feet_air_time, double, N * 6); AL(last_contacts, uint8_t, N * 6); AL(last_contacts_filt, uint8_t, N * 6); AL(base_height, double, N);
 #undef AL
   return e;
 }
@@ -101,6 +114,7 @@ void nmo_env_destroy(nmo_env* e) {
   free(e->data); free(e->scratch); free(e->dof_pos); free(e->dof_vel); free(e->commands); free(e->episode_sums);
   free(e->actions); free(e->prev_actions); free(e->ep_len); free(e->rng_ctr); free(e->blv); free(e->bav); free(e->pg);
   free(e->tibia); free(e->feet); free(e->body); free(e->rew_terms); free(e->reset_buf); free(e->time_out); free(e->noise_u);
+  free(e->feet_air_time); free(e->last_contacts); free(e->last_contacts_filt); free(e->base_height);
   free(e);
 }
 nmo_data* nmo_env_data(nmo_env* e, int i) { return &e->data[i]; }
@@ -128,6 +142,7 @@ static void reset_one(nmo_env* e, int i, const double* u) {
   for (int k = 0; k < NMO_NQ; k++) d->qpos[k] = nm_qpos0[k]; /* :349 model.qpos0 (mjmodel.xml:33) */
   for (int k = 0; k < NMO_NV; k++) d->qvel[k] = 0;                                       /* :350 */
   resample(e, i, u);                                                                     /* :356 */
+  for (int j = 0; j < 6; j++) e->feet_air_time[i * 6 + j] = 0;                           /* :359 (last_contacts* are NOT cleared) */
   e->ep_len[i] = 0;                                                                      /* :360 */
   e->reset_buf[i] = 1;                                                                   /* :361 */
 }
@@ -206,6 +221,7 @@ void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* 
     for (int j = 0; j < 18; j++) { e->dof_pos[i * 18 + j] = d->qpos[7 + j]; e->dof_vel[i * 18 + j] = d->qvel[6 + j]; }
     for (int j = 0; j < 6; j++) { e->tibia[i * 6 + j] = d->sensordata[j]; e->feet[i * 6 + j] = d->sensordata[6 + j]; }
     e->body[i] = d->sensordata[12];
+    e->base_height[i] = d->xipos[1][2]; /* :223 */
     for (int j = 0; j < 6; j++) e->tibia[i * 6 + j] *= (e->feet[i * 6 + j] == 0) ? 1.0 : 0.0; /* :232 */
   }
   /* E4 (env.py:235-236) periodic command resample */
@@ -221,6 +237,12 @@ void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* 
     double fmaxv = e->feet[i * 6];
     for (int j = 1; j < 6; j++) fmaxv = e->feet[i * 6 + j] > fmaxv ? e->feet[i * 6 + j] : fmaxv;
     r |= fmaxv > TERM_CONTACT_FORCE;
+    if (e->tibia_mode == 2) { /* :248-249, on the masked tibia forces of :232 */
+      double tm = e->tibia[i * 6];
+      for (int j = 1; j < 6; j++) tm = e->tibia[i * 6 + j] > tm ? e->tibia[i * 6 + j] : tm;
+      r |= tm > e->tibia_max_force;
+    }
+    if (e->body_mode == 2) r |= e->body[i] > e->body_max_force; /* :250-251 */
     const double* pg = e->pg + 3 * i;
     double nrm = sqrt(pg[0] * pg[0] + pg[1] * pg[1] + pg[2] * pg[2]);
     r |= acos(-pg[2] / nrm) > max_angle;
@@ -239,19 +261,62 @@ void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* 
   for (int i = 0; i < N; i++) {
     double t[NMO_NREW];
     float sq[18];
+    const double *pg = e->pg + 3 * i, *c = e->commands + 3 * i, *v = e->blv + 3 * i, *w = e->bav + 3 * i;
+    memset(t, 0, sizeof t);
     for (int j = 0; j < 18; j++) { float df = e->prev_actions[i * 18 + j] - e->actions[i * 18 + j]; sq[j] = df * df; }
-    t[R_ACTION_RATE] = (double)(np_sum_f32(sq, 18) * (float)e->scale[R_ACTION_RATE]); /* float32 array * python float */
+    if (e->scale[R_ACTION_RATE] != 0) t[R_ACTION_RATE] = (double)(np_sum_f32(sq, 18) * (float)e->scale[R_ACTION_RATE]); /* float32 array * python float */
+    if (e->scale[R_ANG_VEL_XY] != 0) t[R_ANG_VEL_XY] = (w[0] * w[0] + w[1] * w[1]) * e->scale[R_ANG_VEL_XY];              /* :403-405 */
+    if (e->scale[R_BASE_HEIGHT] != 0) {                                                                                  /* :411-413 */
+      double dh = e->base_height[i] - e->base_height_target;
+      t[R_BASE_HEIGHT] = dh * dh * e->scale[R_BASE_HEIGHT];
+    }
     double sum = 0;
-    for (int j = 0; j < 6; j++) sum += e->tibia[i * 6 + j];
-    t[R_BODY_CONTACT] = (sum + e->body[i]) * e->scale[R_BODY_CONTACT];
+    if (e->tibia_mode == 1) for (int j = 0; j < 6; j++) sum += e->tibia[i * 6 + j];                                      /* :479-485 */
+    if (e->body_mode == 1) sum += e->body[i];
+    t[R_BODY_CONTACT] = sum * e->scale[R_BODY_CONTACT];
     sum = 0;
     for (int j = 0; j < 18; j++) { double df = e->dof_pos[i * 18 + j] - default_pos[j % 3]; sum += df * df; }
     t[R_DEFAULT_POS] = sum * e->scale[R_DEFAULT_POS];
     sum = 0;
     for (int j = 0; j < 18; j++) { double acc = (e->dof_vel[i * 18 + j] - prev_dof_vel[i * 18 + j]) / e->dt; sum += acc * acc; }
     t[R_DOF_ACC] = sum * e->scale[R_DOF_ACC];
-    const double *pg = e->pg + 3 * i, *c = e->commands + 3 * i, *v = e->blv + 3 * i, *w = e->bav + 3 * i;
+    if (e->scale[R_DOF_VEL] != 0) {                                                                                      /* :419-421 */
+      sum = 0;
+      for (int j = 0; j < 18; j++) sum += e->dof_vel[i * 18 + j] * e->dof_vel[i * 18 + j];
+      t[R_DOF_VEL] = sum * e->scale[R_DOF_VEL];
+    }
+    if (e->scale[R_FEET_AIR_TIME] != 0) { /* :458-477; stateful, runs only while it is in the reward table */
+      sum = 0;
+      for (int j = 0; j < 6; j++) {
+        int k = i * 6 + j;
+        uint8_t contact = e->feet[k] > 1.0;
+        uint8_t filt = contact | e->last_contacts[k];
+        double air = e->feet_air_time[k] + e->dt;
+        air *= (filt == e->last_contacts_filt[k]) ? 1.0 : 0.0; /* reset air time if contact changes */
+        e->feet_air_time[k] = air;
+        e->last_contacts[k] = contact;
+        e->last_contacts_filt[k] = filt;
+        double single = (air > 1.0 ? 1.0 : 0.0) * (air - 1.0) + (air < 0.5 ? 1.0 : 0.0) * (0.5 - air);
+        sum += single * single;
+      }
+      t[R_FEET_AIR_TIME] = sum * e->scale[R_FEET_AIR_TIME];
+    }
+    if (e->scale[R_FEET_CONTACT] != 0) {                                                                                 /* :491-493 */
+      sum = 0;
+      for (int j = 0; j < 6; j++) {
+        double f = e->feet[i * 6 + j], x = (f - e->max_contact_force) * (f > e->max_contact_force ? 1.0 : 0.0);
+        sum += x * x;
+      }
+      t[R_FEET_CONTACT] = sum * e->scale[R_FEET_CONTACT];
+    }
+    if (e->scale[R_LIN_VEL_Z] != 0) t[R_LIN_VEL_Z] = v[2] * v[2] * e->scale[R_LIN_VEL_Z];                                  /* :399-401 */
     t[R_ORIENTATION] = (pg[0] * pg[0] + pg[1] * pg[1]) * e->scale[R_ORIENTATION];
+    if (e->scale[R_STAND_STILL] != 0) {                                                                                  /* :487-489 */
+      sum = 0;
+      for (int j = 0; j < 18; j++) sum += fabs(e->dof_pos[i * 18 + j] - default_pos[j % 3]);
+      t[R_STAND_STILL] = sum * (sqrt(c[0] * c[0] + c[1] * c[1]) < 0.01 ? 1.0 : 0.0) * e->scale[R_STAND_STILL];
+    }
+    t[R_TORQUES] = 0; /* :415-417: qfrc_applied[-18:] (env.py:222), which nothing ever writes */
     double ea = (c[2] - w[2]) * (c[2] - w[2]);
     t[R_TRACK_ANG] = exp(-ea / TRACKING_SIGMA) * e->scale[R_TRACK_ANG];
     double el = (c[0] - v[0]) * (c[0] - v[0]) + (c[1] - v[1]) * (c[1] - v[1]);
@@ -294,6 +359,23 @@ void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* 
   }
   free(prev_dof_vel);
   e->noise_step++;
+}
+
+void nmo_env_configure(nmo_env* e, const double* reward_scales, int tibia_mode, double tibia_max_force, int body_mode, double body_max_force,
+                       double base_height_target, double max_contact_force) {
+  if (reward_scales) for (int k = 0; k < NMO_NREW; k++) e->scale[k] = reward_scales[k] * e->dt; /* env.py:123-128 */
+  e->tibia_mode = tibia_mode; e->tibia_max_force = tibia_max_force; e->body_mode = body_mode; e->body_max_force = body_max_force;
+  e->base_height_target = base_height_target; e->max_contact_force = max_contact_force;
+}
+void nmo_env_get_feet_state(nmo_env* e, double* air6, uint8_t* last6, uint8_t* filt6) {
+  if (air6) memcpy(air6, e->feet_air_time, sizeof(double) * e->N * 6);
+  if (last6) memcpy(last6, e->last_contacts, e->N * 6);
+  if (filt6) memcpy(filt6, e->last_contacts_filt, e->N * 6);
+}
+void nmo_env_set_feet_state(nmo_env* e, const double* air6, const uint8_t* last6, const uint8_t* filt6) {
+  if (air6) memcpy(e->feet_air_time, air6, sizeof(double) * e->N * 6);
+  if (last6) memcpy(e->last_contacts, last6, e->N * 6);
+  if (filt6) memcpy(e->last_contacts_filt, filt6, e->N * 6);
 }
 
 void nmo_env_set_noise(nmo_env* e, const double* noise_scale_vec66, const double* u) {

@@ -16,9 +16,12 @@ LIB_PATH = os.path.join(HERE, "libnm_oracle.so")
 
 NBODY, NV, NQ, NU, NSENS, MAXCON = 20, 24, 25, 18, 13, 48
 MAXEFC = 4 * MAXCON
-NREW = 8
-REW_NAMES = ["action_rate", "body_contact_forces", "default_position", "dof_acc", "orientation",
-             "tracking_ang_vel", "tracking_lin_vel", "termination"]
+NREW = 16
+# every reward name of the reference config with a _reward_ function behind it (env.py:399-497): alphabetical, termination last
+REW_NAMES = ["action_rate", "ang_vel_xy", "base_height", "body_contact_forces", "default_position", "dof_acc", "dof_vel", "feet_air_time",
+             "feet_contact_forces", "lin_vel_z", "orientation", "stand_still", "torques", "tracking_ang_vel", "tracking_lin_vel", "termination"]
+DEFAULT_SCALES = dict(termination=-200.0, tracking_lin_vel=8.0, tracking_ang_vel=6.0, dof_acc=-2.5e-5, action_rate=-0.02,
+                      body_contact_forces=-5.0, default_position=-0.01, orientation=-5.0)   # config.py:78-86; all others 0
 
 d_ = C.c_double
 
@@ -88,6 +91,9 @@ def lib():
         L.nmo_env_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.nmo_env_step.argtypes = [C.c_void_p] + [C.c_void_p] * 8
         L.nmo_env_set_noise.argtypes = [C.c_void_p] * 3
+        L.nmo_env_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double]
+        L.nmo_env_get_feet_state.argtypes = [C.c_void_p] * 4
+        L.nmo_env_set_feet_state.argtypes = [C.c_void_p] * 4
         L.nmo_env_get_state.argtypes = [C.c_void_p] * 4
         L.nmo_env_set_state.argtypes = [C.c_void_p] * 4
         L.nmo_env_get_buffers.argtypes = [C.c_void_p] * 7
@@ -152,6 +158,24 @@ class OracleEnv:
         if getattr(self, "h", None):
             self.L.nmo_env_destroy(self.h)
             self.h = None
+
+    def configure(self, reward_scales=None, tibia_contact_mode=1, tibia_max_contact_force=2.0, body_contact_mode=1,
+                  body_max_contact_force=2.0, base_height_target=0.1, max_contact_force=10.0):
+        """Non-default reward table (dict name -> RAW config scale; missing names = 0) and contact modes (config.py:17-21,77-100)."""
+        sc = None
+        if reward_scales is not None:
+            sc = np.array([float(reward_scales.get(n, 0.0)) for n in REW_NAMES])
+        self.L.nmo_env_configure(self.h, _ptr(sc), tibia_contact_mode, tibia_max_contact_force, body_contact_mode, body_max_contact_force,
+                                 base_height_target, max_contact_force)
+
+    def get_feet_state(self):
+        air, last, filt = np.empty((self.N, 6)), np.empty((self.N, 6), np.uint8), np.empty((self.N, 6), np.uint8)
+        self.L.nmo_env_get_feet_state(self.h, _ptr(air), _ptr(last), _ptr(filt))
+        return air, last, filt
+
+    def set_feet_state(self, air, last, filt):
+        air, last, filt = np.ascontiguousarray(air, np.float64), np.ascontiguousarray(last, np.uint8), np.ascontiguousarray(filt, np.uint8)
+        self.L.nmo_env_set_feet_state(self.h, _ptr(air), _ptr(last), _ptr(filt))
 
     def reset_idx(self, ids=None, cmd_u=None):
         if ids is None:

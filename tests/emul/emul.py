@@ -34,6 +34,8 @@ def lib():
         L.emu_set.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_set_noise.argtypes = [C.c_void_p] * 3
         L.emu_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+        L.emu_configure.argtypes = [C.c_void_p] * 3
+        L.emu_feet.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
         L.emu_eplen.argtypes = [C.c_void_p]
         L.emu_eplen.restype = C.POINTER(C.c_int64)
         _lib = L
@@ -44,7 +46,9 @@ def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-WHAT = dict(qpos=(0, 25), qvel=(1, 24), qwarm=(2, 24), dofpos=(3, 18), dofvel=(4, 18), act=(5, 18), cmd=(6, 3), epsum=(7, 8))
+WHAT = dict(qpos=(0, 25), qvel=(1, 24), qwarm=(2, 24), dofpos=(3, 18), dofvel=(4, 18), act=(5, 18), cmd=(6, 3), epsum=(7, 16))
+REW_NAMES = ["action_rate", "ang_vel_xy", "base_height", "body_contact_forces", "default_position", "dof_acc", "dof_vel", "feet_air_time",
+             "feet_contact_forces", "lin_vel_z", "orientation", "stand_still", "torques", "tracking_ang_vel", "tracking_lin_vel", "termination"]
 
 
 class EmulEnv:
@@ -68,6 +72,23 @@ class EmulEnv:
         w, k = WHAT[name]
         v = np.ascontiguousarray(val, np.float64).reshape(self.N, k)
         self.L.emu_set(self.h, w, _p(v))
+
+    def configure(self, reward_scales, tibia_contact_mode=1, tibia_max_contact_force=2.0, body_contact_mode=1, body_max_contact_force=2.0,
+                  base_height_target=0.1, max_contact_force=10.0):
+        sc = np.array([float(reward_scales.get(n, 0.0)) for n in REW_NAMES])
+        m = np.array([tibia_contact_mode, tibia_max_contact_force, body_contact_mode, body_max_contact_force, base_height_target, max_contact_force], np.float64)
+        self.L.emu_configure(self.h, _p(sc), _p(m))
+
+    def get_feet_state(self):
+        air, fl = np.zeros((self.N, 6)), np.zeros(self.N, np.int32)
+        self.L.emu_feet(self.h, 0, _p(air), _p(fl))
+        bits = (fl[:, None] >> np.arange(12)[None, :]) & 1
+        return air, bits[:, :6].astype(np.uint8), bits[:, 6:].astype(np.uint8)
+
+    def set_feet_state(self, air, last, filt):
+        air = np.ascontiguousarray(air, np.float64)
+        fl = ((np.asarray(last, np.int32) << np.arange(6)).sum(1) | (np.asarray(filt, np.int32) << (6 + np.arange(6))).sum(1)).astype(np.int32)
+        self.L.emu_feet(self.h, 1, _p(air), _p(fl))
 
     def set_noise(self, vec=None, u=None):
         f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)
@@ -93,7 +114,7 @@ class EmulEnv:
         done = np.zeros(N, np.int64)
         to = np.zeros(N, np.float32)
         dbg = np.zeros((N, 256)) if want_dbg else None
-        ssum = np.zeros(8)
+        ssum = np.zeros(16)
         scnt = np.zeros(2, np.int32)
         self.L.emu_step(self.h, _p(a), _p(cu), _p(obs), _p(rew), _p(done), _p(to), nsub, int(physics_only), _p(dbg), _p(ssum), _p(scnt))
         self.dbg, self.stat_sum, self.stat_cnt = dbg, ssum, scnt

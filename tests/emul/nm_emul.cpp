@@ -19,6 +19,8 @@ struct EmuBase {
   virtual int64_t* eplen() = 0;
   virtual void set_noise(const double* vec, const double* u) = 0;
   virtual void record(int env, double* out50) = 0;
+  virtual void configure(const double* scales, const double* modes6) = 0;
+  virtual void feet(int set, double* air, int* flags) = 0;
 };
 
 template <class real> struct Emu : EmuBase {
@@ -28,7 +30,8 @@ template <class real> struct Emu : EmuBase {
   std::vector<real> qpos, qvel, qwarm, dofpos, dofvel, act, cmd, epsum;
   std::vector<int64_t> ep;
   std::vector<uint32_t> ctr;
-  std::vector<int> hcache;
+  std::vector<int> hcache, feetflags;
+  std::vector<real> feetair;
   uint64_t seed;
   int64_t off;
   int G = 1;
@@ -44,14 +47,26 @@ template <class real> struct Emu : EmuBase {
     rec_env = env;
     if (out50) for (int i = 0; i < 50; i++) out50[i] = (double)rec[i];
   }
+  void configure(const double* scales, const double* m) override {   // raw reward scales [kNREW] + (tibia mode, max, body mode, max, base height target, max contact force)
+    nmhost::EnvConfig cfg;
+    for (int k = 0; k < nm::kNREW; k++) cfg.rew_scales[k] = scales[k];
+    cfg.tibia_contact_mode = (int)m[0]; cfg.tibia_max_contact_force = m[1]; cfg.body_contact_mode = (int)m[2]; cfg.body_max_contact_force = m[3];
+    cfg.base_height_target = m[4]; cfg.max_contact_force = m[5];
+    T.fill_scalars(M, cfg);
+  }
+  void feet(int set, double* air, int* flags) override {
+    for (size_t i = 0; i < feetair.size(); i++) { if (set) feetair[i] = (real)air[i]; else air[i] = (double)feetair[i]; }
+    for (int i = 0; i < N; i++) { if (set) feetflags[i] = flags[i]; else flags[i] = feetflags[i]; }
+  }
   Emu(int n, uint64_t s, int64_t o, int g) : N(n), seed(s), off(o), G(g) {
     T.build();
     nmhost::EnvConfig cfg;
     T.fill_scalars(M, cfg);
+    feetair.assign((size_t)N * 6, 0); feetflags.assign(N, 0);
     M.hullv = T.hullv.data(); M.hullnv = T.hullnv.data();
     qpos.assign((size_t)N * 25, 0); qvel.assign((size_t)N * 24, 0); qwarm.assign((size_t)N * 24, 0);
     dofpos.assign((size_t)N * 18, 0); dofvel.assign((size_t)N * 18, 0); act.assign((size_t)N * 18, 0);
-    cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * 8, 0); ep.assign(N, 0); ctr.assign(N, 0); hcache.assign((size_t)N * 8, 0);
+    cmd.assign((size_t)N * 3, 0); epsum.assign((size_t)N * nm::kNREW, 0); ep.assign(N, 0); ctr.assign(N, 0); hcache.assign((size_t)N * 8, 0);
     for (int i = 0; i < N; i++)
       for (int j = 0; j < 25; j++) qpos[(size_t)i * 25 + j] = T.qpos0[j];
   }
@@ -67,13 +82,13 @@ template <class real> struct Emu : EmuBase {
   int64_t* eplen() override { return ep.data(); }
   void step(const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done, float* to, int nsub, int physics_only,
             double* dbg, double* stat_sum, int* stat_cnt) override {
-    std::vector<real> cu, dbgr((size_t)N * nm::kDbgN, 0), ssum(8, 0);
+    std::vector<real> cu, dbgr((size_t)N * nm::kDbgN, 0), ssum(nm::kNREW, 0);
     if (cmd_u) { cu.resize((size_t)N * 4); for (size_t i = 0; i < cu.size(); i++) cu[i] = (real)cmd_u[i]; }
     int scnt[4] = {0, 0, 0, 0};
     nm::Args<real> A{};
     A.N = N; A.seed = seed; A.env_offset = off;
     A.qpos = qpos.data(); A.qvel = qvel.data(); A.qwarm = qwarm.data(); A.dofpos = dofpos.data(); A.dofvel = dofvel.data();
-    A.act = act.data(); A.cmd = cmd.data(); A.epsum = epsum.data(); A.eplen = ep.data(); A.rngctr = ctr.data(); A.hullcache = hcache.data();
+    A.act = act.data(); A.cmd = cmd.data(); A.epsum = epsum.data(); A.feetair = feetair.data(); A.feetflags = feetflags.data(); A.eplen = ep.data(); A.rngctr = ctr.data(); A.hullcache = hcache.data();
     A.actions = actions; A.cmd_u = cmd_u ? cu.data() : nullptr;
     A.obs = obs; A.rew = rew; A.timeout_now = to; A.done = done; A.stat_sum = ssum.data(); A.stat_cnt = scnt;
     A.dbg = dbg ? dbgr.data() : nullptr; A.nsub = nsub; A.physics_only = physics_only;
@@ -89,7 +104,7 @@ template <class real> struct Emu : EmuBase {
       for (int wv = 0; wv * 2 < N; wv++) nm::wave_step<real, 2>(sh, M, A, wv);
     }
     if (dbg) for (size_t i = 0; i < dbgr.size(); i++) dbg[i] = (double)dbgr[i];
-    if (stat_sum) for (int k = 0; k < 8; k++) stat_sum[k] = (double)ssum[k];
+    if (stat_sum) for (int k = 0; k < nm::kNREW; k++) stat_sum[k] = (double)ssum[k];
     if (stat_cnt) { stat_cnt[0] = scnt[0]; stat_cnt[1] = scnt[1]; }
   }
 };
@@ -110,5 +125,8 @@ void emu_set(void* h, int what, const double* in) { ((EmuBase*)h)->set(what, in)
 int64_t* emu_eplen(void* h) { return ((EmuBase*)h)->eplen(); }
 void emu_set_noise(void* h, const double* vec, const double* u) { ((EmuBase*)h)->set_noise(vec, u); }
 void emu_record(void* h, int env, double* out50) { ((EmuBase*)h)->record(env, out50); }
+void emu_configure(void* h, const double* scales, const double* modes6) { ((EmuBase*)h)->configure(scales, modes6); }
+void emu_feet(void* h, int set, double* air, int* flags) { ((EmuBase*)h)->feet(set, air, flags); }
+int emu_nrew() { return nm::kNREW; }
 int emu_dbg_n() { return nm::kDbgN; }
 }

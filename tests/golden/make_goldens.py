@@ -123,7 +123,7 @@ class RandRecorder:
         np.random.rand = self._orig
 
 
-def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False):
+def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False, cfg_fn=None):
     import torch
     from envs.nightmare_v3_config import NightmareV3Config
     from envs.nightmare_v3_env import NightmareV3Env
@@ -133,12 +133,14 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False):
     cfg.viewer.render = False
     cfg.viewer.record_states = False
     cfg.noise.add_noise = noise
+    if cfg_fn is not None:
+        cfg_fn(cfg)
     np.random.seed(seed)
     env = NightmareV3Env(cfg, log_dir="/tmp/nm_golden_logs", num_threads=1)
     rng = np.random.default_rng(seed + 1000)
     log = {k: [] for k in ("actions", "obs", "rew", "done", "time_outs", "commands", "ep_len", "cmd_u", "qpos", "qvel", "qacc_warmstart",
                            "base_lin_vel", "base_ang_vel", "projected_gravity", "tibia", "feet", "body", "dof_pos", "dof_vel",
-                           "episode_sums", "ep_stats", "nreset", "noise_u")}
+                           "episode_sums", "ep_stats", "nreset", "noise_u", "feet_air_time", "last_contacts", "last_contacts_filt", "base_heights")}
     # reset() = reset_idx(all) + step(zeros)   (env.py:392-396)
     with RandRecorder() as rr:
         env.reset_idx(np.arange(N))
@@ -148,7 +150,8 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False):
     init = dict(qpos=np.stack([d.qpos.copy() for d in env.data]), qvel=np.stack([d.qvel.copy() for d in env.data]),
                 qacc_warmstart=np.stack([d.qacc_warmstart.copy() for d in env.data]),
                 ep_len=env.episode_length_buf.numpy().copy(), commands=env.commands.copy(),
-                dof_pos=env.dof_pos.copy(), dof_vel=env.dof_vel.copy())
+                dof_pos=env.dof_pos.copy(), dof_vel=env.dof_vel.copy(), feet_air_time=env.feet_air_time.copy(),
+                last_contacts=np.array(env.last_contacts, np.uint8), last_contacts_filt=np.array(env.last_contacts_filt, np.uint8))
     names = list(env.episode_sums.keys())
     for t in range(steps):
         a = np.zeros((N, 18), np.float32) if (t == 0 and action_fn is None and name == "reset_rollout") else None
@@ -187,6 +190,10 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False):
                         ("tibia", "tibia_contact_forces"), ("feet", "feet_contact_forces"), ("body", "body_contact_force"),
                         ("dof_pos", "dof_pos"), ("dof_vel", "dof_vel")):
             log[k].append(np.array(getattr(env, attr), dtype=np.float64, copy=True))
+        log["feet_air_time"].append(env.feet_air_time.copy())
+        log["last_contacts"].append(np.array(env.last_contacts, np.uint8))
+        log["last_contacts_filt"].append(np.array(env.last_contacts_filt, np.uint8))
+        log["base_heights"].append(env.base_heights.copy())
         log["episode_sums"].append(np.stack([env.episode_sums[k].copy() for k in names]))
         if len(rst_ids):
             log["ep_stats"].append(np.array([float(extras["episode"]["rew_" + k]) for k in names]))
@@ -200,6 +207,13 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False):
     out["max_episode_length"] = np.array(env.max_episode_length)
     out["dt"] = np.array(env.dt)
     out["noise_scale_vec"] = env.noise_scale_vec
+    # the configuration the scenario ran with (raw config values; the tests configure the oracle / the HIP env from these)
+    from envs.helpers import class_to_dict
+    raw = class_to_dict(cfg.rewards.scales)
+    out["cfg_reward_names"] = np.array(list(raw.keys()))
+    out["cfg_reward_scales"] = np.array([float(raw[k]) for k in raw])
+    out["cfg_modes"] = np.array([cfg.env.tibia_contact_mode, cfg.env.tibia_max_contact_force, cfg.env.body_contact_mode,
+                                 cfg.env.body_max_contact_force, cfg.rewards.base_height_target, cfg.rewards.max_contact_force], dtype=np.float64)
     for k, v in init.items():
         out["init_" + k] = v
     path = os.path.join(ROOT, "tests", "golden", f"env_{name}.npz")
@@ -255,8 +269,66 @@ def main_noise():
                  action_fn=lambda t, rng, N: rng.uniform(-1, 1, (N, 18)).astype(np.float32) * 2.0)
 
 
+def _setup_mixed(env):
+    """Upright, tilted (terminate at once), dropped and belly-down robots; zero commands for some (stand_still)."""
+    for i, d in enumerate(env.data):
+        ang = [0.0, 0.0, 1.3, 0.0, 0.7, 0.0, 2.2, 0.3][i]
+        ax = np.array([[1, 0, 0], [0, 1, 0], [1, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 0], [0, 1, 0]][i], dtype=float)
+        ax /= np.linalg.norm(ax)
+        q = d.qpos.copy()
+        q[3] = np.cos(ang / 2)
+        q[4:7] = np.sin(ang / 2) * ax
+        q[2] = [0.15, 0.2, 0.25, 0.5, 0.2, 0.12, 0.3, 0.18][i]
+        if i in (3, 5):   # legs pointing down: feet take the load
+            q[7:] = np.tile([0.0, -0.9, 0.6], 6)
+        if i == 1:        # legs folded up: the belly lands
+            q[7:] = np.tile([0.0, 0.9, -0.3], 6)
+        d.qpos = q
+        v = np.zeros(24)
+        if i == 3:
+            v[2] = -3.0
+        d.qvel = v
+    env.commands[0:3] = 0.0
+
+
+def main_rewards():
+    """(e) every reward function of the reference in the table (the scales config.py:88-96 keeps as comments), (f)/(g) contact
+    modes 2 (terminate on tibia / body contact) and 0."""
+    install_stub()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+
+    def all_rewards(cfg):
+        sc = cfg.rewards.scales
+        sc.lin_vel_z, sc.ang_vel_xy, sc.feet_air_time, sc.torques = -2.0, -5.0, -4.0, -0.00001
+        sc.base_height, sc.feet_contact_forces, sc.dof_vel, sc.stand_still = -2000.0, -0.05, -0.001, -1.0
+
+    def act(t, rng, N):   # slow sweeps + noise so that feet lift off and land (feet_air_time changes state)
+        ph = 0.35 * t + np.arange(N)[:, None] * 0.7 + np.arange(18)[None, :] * 1.1
+        return (3.0 * np.sin(ph) + rng.uniform(-1, 1, (N, 18))).astype(np.float32)
+
+    run_scenario("allrewards", N=8, steps=140, seed=6, setup=_setup_mixed, action_fn=act, cfg_fn=all_rewards)
+
+    def modes22(cfg):
+        cfg.env.tibia_contact_mode = 2
+        cfg.env.body_contact_mode = 2
+        cfg.rewards.scales.feet_air_time = -4.0
+
+    run_scenario("modes22", N=8, steps=60, seed=7, setup=_setup_mixed, action_fn=act, cfg_fn=modes22)
+
+    def modes01(cfg):
+        cfg.env.tibia_contact_mode = 0
+        cfg.env.body_contact_mode = 1
+        cfg.rewards.scales.tracking_ang_vel = 0       # a default term dropped from the table
+        cfg.rewards.scales.dof_vel = -0.001
+
+    run_scenario("modes01", N=8, steps=40, seed=8, setup=_setup_mixed, action_fn=act, cfg_fn=modes01)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "noise":
         main_noise()
+    elif len(sys.argv) > 1 and sys.argv[1] == "rewards":
+        main_rewards()
     else:
         main()

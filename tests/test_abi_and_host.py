@@ -35,9 +35,19 @@ def test_default_config_matches_reference_defaults(hip_lib_path):
     L.nm_default_config(ctypes.byref(c))
     assert c.decimation == 2 and c.p_gain == 20 and abs(c.action_scale - 0.2) < 1e-15
     assert abs(c.default_pos[1] - np.pi / 5) < 1e-15 and c.termination_contact_force == 160
-    assert _lib.reward_names() == ["action_rate", "body_contact_forces", "default_position", "dof_acc", "orientation",
-                                   "tracking_ang_vel", "tracking_lin_vel", "termination"]
-    assert list(c.reward_scales) == [-0.02, -5.0, -0.01, -2.5e-5, -5.0, 6.0, 8.0, -200.0]
+    # every reward name of the reference config with a _reward_ function (env.py:399-497): alphabetical, termination last
+    names = _lib.reward_names()
+    assert names == ["action_rate", "ang_vel_xy", "base_height", "body_contact_forces", "default_position", "dof_acc", "dof_vel",
+                     "feet_air_time", "feet_contact_forces", "lin_vel_z", "orientation", "stand_still", "torques", "tracking_ang_vel",
+                     "tracking_lin_vel", "termination"]
+    from nightmare_rl_amd.envs.helpers import class_to_dict
+    from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config
+    cfg = NightmareV3Config()
+    ref = class_to_dict(cfg.rewards.scales)
+    assert dict(zip(names, c.reward_scales)) == {n: float(ref[n]) for n in names}
+    assert sorted(set(ref) - set(names)) == ["collision", "feet_stumble"]       # config names with no function upstream (config.py:95-96)
+    assert (c.tibia_contact_mode, c.tibia_max_contact_force, c.body_contact_mode, c.body_max_contact_force) == (1, 2.0, 1, 2.0)
+    assert (c.base_height_target, c.max_contact_force) == (cfg.rewards.base_height_target, cfg.rewards.max_contact_force) == (0.1, 10.0)
 
 
 def test_create_fails_loudly_without_gpu(hip_lib_path):

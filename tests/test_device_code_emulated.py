@@ -6,13 +6,19 @@ import pytest
 
 from conftest import load_golden
 
-SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz", "env_noise.npz"]
+SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz", "env_noise.npz",
+             "env_allrewards.npz", "env_modes22.npz", "env_modes01.npz"]   # every reward function in the table; contact modes 2 and 0
 
 
 def teacher_forced(make_env, g, steps=None):
     """Load the golden pre-step state each step, step once, return per-env max |obs error|, |rew error| and flags."""
     N, T = g["actions"].shape[1], g["actions"].shape[0] if steps is None else steps
     e = make_env(N)
+    from test_oracle_env_golden import golden_config
+    kw = golden_config(g)
+    if kw is not None:
+        e.configure(**kw)
+    feet = (g["init_feet_air_time"], g["init_last_contacts"], g["init_last_contacts_filt"]) if "feet_air_time" in g else None
     qpos, qvel, qw = g["init_qpos"], g["init_qvel"], g["init_qacc_warmstart"]
     dofpos, dofvel, cmd, ep = g["init_dof_pos"], g["init_dof_vel"], g["init_commands"], g["init_ep_len"]
     act = np.zeros((N, 18))
@@ -21,6 +27,8 @@ def teacher_forced(make_env, g, steps=None):
         e.set("qpos", qpos); e.set("qvel", qvel); e.set("qwarm", qw); e.set("dofpos", dofpos); e.set("dofvel", dofvel)
         e.set("cmd", cmd); e.set("act", act)
         e.eplen[:] = ep
+        if feet is not None:
+            e.set_feet_state(*feet)
         if "noise_u" in g and g["noise_u"].shape[1] > 0:
             e.set_noise(g["noise_scale_vec"], g["noise_u"][t])
         obs, rew, done, to = e.step(g["actions"][t], cmd_u=g["cmd_u"][t])
@@ -29,6 +37,13 @@ def teacher_forced(make_env, g, steps=None):
         flags += int((done != g["done"][t]).sum()) + int((to != g["time_outs"][t]).sum())
         state.append(max(np.abs(e.get("qpos") - g["qpos"][t]).max(), np.abs(e.get("qvel") - g["qvel"][t]).max()))
         np.testing.assert_array_equal(e.eplen, g["ep_len"][t])
+        if feet is not None and kw["reward_scales"].get("feet_air_time", 0) != 0:
+            air, last, filt = e.get_feet_state()
+            np.testing.assert_allclose(air, g["feet_air_time"][t], atol=1e-5)
+            np.testing.assert_array_equal(last, g["last_contacts"][t])
+            np.testing.assert_array_equal(filt, g["last_contacts_filt"][t])
+        if feet is not None:
+            feet = (g["feet_air_time"][t], g["last_contacts"][t], g["last_contacts_filt"][t])
         qpos, qvel, qw = g["qpos"][t], g["qvel"][t], g["qacc_warmstart"][t]
         dofpos, dofvel, cmd, ep = g["dof_pos"][t], g["dof_vel"][t], g["commands"][t], g["ep_len"][t]
         act = np.clip(g["actions"][t].astype(np.float32) * np.float32(0.2), -1, 1).astype(np.float64)
