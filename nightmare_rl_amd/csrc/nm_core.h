@@ -36,8 +36,10 @@ constexpr int kLinkN = 25;             // per-link constants: bpos3 bR9 axis3 ip
 constexpr int kLegN = 3 * kLinkN;      // per-leg constants
 constexpr int kBaseN = 10;             // ipos3 Ibody6 mass1
 constexpr int kColN = 24;              // per colliding mesh: center3 rbound invweight0 nvert vadr pad | obb: center3 axes9 half3 pad
-constexpr int kMaxCon = 16;            // contacts kept per env (rows = 4*kMaxCon = one per lane)
+constexpr int kMaxCon = 16;            // contacts the register-resident solver takes (rows = 4*kMaxCon = one per lane)
 constexpr int kMaxRow = 4 * kMaxCon;
+constexpr int kMaxConBig = 44;         // contact slots per env; the model can produce 7 meshes x 4 floor contacts + 15 tibia pairs = 43
+constexpr int kBigSlots = (4 * kMaxConBig + NM_WAVE - 1) / NM_WAVE;   // rows per lane of the matrix-free solver used beyond kMaxCon
 constexpr int kJRow = 16;              // LDS row: Jb6 Jl3 leg | Jm3 leg1 (body1 side of a tibia-tibia contact) pad2
 // every reward name of the reference config that has a _reward_ function (env.py:399-497), in the order class_to_dict yields them
 // (dir() = alphabetical, helpers.py:7); termination last because step() adds it last (env.py:285-288)
@@ -98,6 +100,7 @@ template <class real> struct Args {
   int* stat_cnt;         // [4]: #resets this step, #contacts dropped (contact cap), #bad-state resets (mj_check*), #hull-search fallbacks
   // end of step, done by whichever wave finishes last (device build): extras refreshed only when >= 1 env reset (env.py:344-371)
   int* wave_done;        // [1] waves that have published their results in this launch
+  int *nto, *to_list;    // [1], [N]: envs that timed out in this launch (what the closing wave turns into extras['time_outs'])
   float *ep_stats, *time_outs;   // [kNREW] extras['episode'], [N] extras['time_outs']
   long long* counters;   // [3] running totals of stat_cnt[1..3]
   real* dbg;             // optional [N][kDbgN]
@@ -124,12 +127,19 @@ template <class real> struct Sh {
   real Minv[kNLEG * 6], W[kNLEG * 18], Lb[15], Dbi[6];      // factor of M
   real MinvH[kNLEG * 6], WH[kNLEG * 18], LbH[15], DbiH[6];  // factor of M + h kv I
   real qas[24], qfs[24], qfc[24];
-  real cpos[kMaxCon * 3], cdist[kMaxCon], cnrm[kMaxCon * 3];
-  int cleg[kMaxCon], cleg1[kMaxCon];   // leg of body2 (-1 = base), leg of body1 (-1 = world/floor)
+  real vv[24];                    // M^-1 J' f of the matrix-free solver (envs with more than kMaxCon contacts)
   real sens[16], cvb[6];
   real bh[2];                     // xipos[1][2] of the last forward pass (env.py:223)
   real mbb[36], sc[36];           // base block of M and its Schur complement (upper triangles)
-  real legtmp[kNLEG * 66];        // per-leg staging between the forward and backward chain passes: 3 x (S6 I10 f6)
+  // per-leg staging between the forward and backward chain passes of stage A: 3 x (S6 I10 f6). Stages B and C reuse it for the
+  // contact list (stage A of an env is over before its collision starts): kMaxConBig x (pos3 normal3 dist, leg of body2 (-1 = base),
+  // leg of body1 (-1 = world/floor))
+  real legtmp[kNLEG * 66];
+  NM_FN real* cpos() { return legtmp; }
+  NM_FN real* cnrm() { return legtmp + 3 * kMaxConBig; }
+  NM_FN real* cdist() { return legtmp + 6 * kMaxConBig; }
+  NM_FN int* cleg() { return reinterpret_cast<int*>(legtmp + 7 * kMaxConBig); }
+  NM_FN int* cleg1() { return reinterpret_cast<int*>(legtmp + 8 * kMaxConBig); }
   real efc_f[kMaxRow];
 #ifdef NM_DEBUG_SOLVER
   real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
@@ -144,6 +154,7 @@ template <class real> struct Sh {
   int hcache[8];                  // support vertex of each colliding mesh found last time (warm start of the hull search)
 };
 
+static_assert(kNLEG * 66 >= 9 * kMaxConBig, "contact list must fit the leg staging area");
 // LDS of one wavefront: G env images (the leg-lane stages run all G envs at once, lanes 8g..8g+5 = legs of env g; collision,
 // constraints and the env epilogue take the envs one after the other on all 64 lanes) + one shared row buffer.
 template <class real, int G> struct ShW {
@@ -286,6 +297,13 @@ NM_FN uint32_t rand_u24_bits(uint64_t seed, uint64_t genv, uint32_t ctr) {
   x ^= x >> 31;
   return (uint32_t)(x >> 40);
 }
+
+// Cross-wave results (episode statistics, counters, the time-out list) travel through device-scope atomics only. A wave consumes
+// the value every such atomic returns before it takes its end-of-step ticket (k_env_step), so they have been performed at the
+// coherence point by then - no release fence, i.e. no L2 write-back per wave (measured: a __threadfence() per wave cost 40 us of 101).
+#ifndef NM_EMUL
+template <class T> NM_FN void nm_consume(T x) { asm volatile("" ::"v"(x) : "memory"); }
+#endif
 
 // Optional in-kernel stage timing (build with -DNM_STAMPS; measurement builds only, never the shipped library):
 // lane 0 of every wave adds the s_memtime ticks since its previous stamp to g_stamps[k].
@@ -910,12 +928,12 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
     real depth, dir[3], pos[3];
     if (!mpr_penetration(sh, M, h1, h2, &depth, dir, pos)) continue;
     if (!(depth > real(0))) continue;
-    if (ncon >= kMaxCon) { *dropped += 1; continue; }
-    sh.cpos[3 * ncon] = pos[0]; sh.cpos[3 * ncon + 1] = pos[1]; sh.cpos[3 * ncon + 2] = pos[2];
-    sh.cnrm[3 * ncon] = dir[0]; sh.cnrm[3 * ncon + 1] = dir[1]; sh.cnrm[3 * ncon + 2] = dir[2];
-    sh.cdist[ncon] = -depth;
-    sh.cleg[ncon] = h2 - 1;
-    sh.cleg1[ncon] = h1 - 1;
+    if (ncon >= kMaxConBig) { *dropped += 1; continue; }   // cannot happen: see kMaxConBig
+    sh.cpos()[3 * ncon] = pos[0]; sh.cpos()[3 * ncon + 1] = pos[1]; sh.cpos()[3 * ncon + 2] = pos[2];
+    sh.cnrm()[3 * ncon] = dir[0]; sh.cnrm()[3 * ncon + 1] = dir[1]; sh.cnrm()[3 * ncon + 2] = dir[2];
+    sh.cdist()[ncon] = -depth;
+    sh.cleg()[ncon] = h2 - 1;
+    sh.cleg1()[ncon] = h1 - 1;
     sh.anypair = 1;
     ncon++;
   }
@@ -1054,25 +1072,25 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     const V<int> rank = lane_rank(m);
     const VB self = lane == kSelfLane;
     const V<int> slot = sel(self, V<int>(total), rank + (total + 1));
-    const VB wr = VB(hitg) & (self | (ok & (rank < 3))) & (slot < kMaxCon);
+    const VB wr = VB(hitg) & (self | (ok & (rank < 3))) & (slot < kMaxConBig);
     const V<int> sl = sel(wr, slot, V<int>(0));
     const vr cd = sel(self, vr(dist), pnt[2] + bz);
-    stsv(sh.cpos, sl * 3, pnt[0], wr);
-    stsv(sh.cpos, sl * 3 + 1, pnt[1], wr);
-    stsv(sh.cpos, sl * 3 + 2, pnt[2] - real(0.5) * cd, wr);
-    stsv(sh.cdist, sl, cd, wr);
-    stsv(sh.cleg, sl, g - 1, wr);
-    stsv(sh.cleg1, sl, -1, wr);
-    stsv(sh.cnrm, sl * 3, real(0), wr);
-    stsv(sh.cnrm, sl * 3 + 1, real(0), wr);
-    stsv(sh.cnrm, sl * 3 + 2, real(1), wr);
+    stsv(sh.cpos(), sl * 3, pnt[0], wr);
+    stsv(sh.cpos(), sl * 3 + 1, pnt[1], wr);
+    stsv(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr);
+    stsv(sh.cdist(), sl, cd, wr);
+    stsv(sh.cleg(), sl, g - 1, wr);
+    stsv(sh.cleg1(), sl, -1, wr);
+    stsv(sh.cnrm(), sl * 3, real(0), wr);
+    stsv(sh.cnrm(), sl * 3 + 1, real(0), wr);
+    stsv(sh.cnrm(), sl * 3 + 2, real(1), wr);
     const int ng = hitg ? 1 + nextra : 0;
-    const int c0 = vmin(total, kMaxCon), c1 = vmin(total + ng, kMaxCon);
+    const int c0 = vmin(total, kMaxConBig), c1 = vmin(total + ng, kMaxConBig);
     sh.cstart[g] = c0;
     sh.ccnt[g] = c1 - c0;
     total += ng;
   }
-  const int ncon = vmin(total, kMaxCon);
+  const int ncon = vmin(total, kMaxConBig);
   *dropped += total - ncon;
   sh.ncon = ncon;
   sh.anypair = 0;
@@ -1111,15 +1129,15 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   const VB act = lane < nefc;
   const V<int> c = sel(act, lane >> 2, V<int>(0));
   const V<int> tk = (lane >> 1) & 1, sg = lane & 1;
-  vr cp[3] = {ldsv(sh.cpos, c * 3), ldsv(sh.cpos, c * 3 + 1), ldsv(sh.cpos, c * 3 + 2)};
-  vr dist = ldsv(sh.cdist, c);
-  V<int> L = ldsv(sh.cleg, c);
+  vr cp[3] = {ldsv(sh.cpos(), c * 3), ldsv(sh.cpos(), c * 3 + 1), ldsv(sh.cpos(), c * 3 + 2)};
+  vr dist = ldsv(sh.cdist(), c);
+  V<int> L = ldsv(sh.cleg(), c);
   const VB onleg = L >= 0;
   const V<int> Lc = vmax(L, V<int>(0));
   // tibia-tibia contacts (rare) carry a second leg (body1) and a general frame; floor-only envs skip all of that
   constexpr bool anypair = PAIR;  // floor-only envs (the common case) compile without the second-body terms
   V<int> L1 = V<int>(-1);
-  if (anypair) L1 = ldsv(sh.cleg1, c);
+  if (anypair) L1 = ldsv(sh.cleg1(), c);
   const VB onleg1 = L1 >= 0;
   const V<int> Lc1 = vmax(L1, V<int>(0));
   // Contact frame (mju_makeFrame): floor contacts have n=(0,0,1), t1=(0,1,0), t2=(-1,0,0). Lane q of a contact's quad first
@@ -1130,7 +1148,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr nrm[3] = {vr(real(0)), vr(real(0)), vr(real(1))};
   vr e[3] = {sel(q4 == 2, vr(real(-1)), vr(real(0))), sel(q4 == 1, vr(real(1)), vr(real(0))), sel((q4 == 0) | (q4 == 3), vr(real(1)), vr(real(0)))};
   if (anypair) {
-    nrm[0] = ldsv(sh.cnrm, c * 3); nrm[1] = ldsv(sh.cnrm, c * 3 + 1); nrm[2] = ldsv(sh.cnrm, c * 3 + 2);
+    nrm[0] = ldsv(sh.cnrm(), c * 3); nrm[1] = ldsv(sh.cnrm(), c * 3 + 1); nrm[2] = ldsv(sh.cnrm(), c * 3 + 2);
     VB usey = (nrm[1] < vr(real(0.5))) & (nrm[1] > vr(real(-0.5)));
     vr y0[3] = {vr(real(0)), sel(usey, vr(real(1)), vr(real(0))), sel(usey, vr(real(0)), vr(real(1)))};
     vr dt = nrm[1] * y0[1] + nrm[2] * y0[2];
@@ -1291,11 +1309,11 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
 #pragma unroll
   for (int cc = 0; cc < kMaxCon; cc++) {
     if (cc < ncon) {
-      const int Lcc = uniform(sh.cleg[cc]);
+      const int Lcc = uniform(sh.cleg()[cc]);
       const VB same = onleg & (L == Lcc);
       VB s01 = VB(false), s10 = VB(false), s11 = VB(false);
       if (anypair) {
-        const int L1cc = uniform(sh.cleg1[cc]);
+        const int L1cc = uniform(sh.cleg1()[cc]);
         s01 = onleg1 & (L1 == Lcc);      // row's body2 leg meets this lane's body1 leg
         s10 = onleg & (L == L1cc);       // row's body1 leg meets this lane's body2 leg
         s11 = onleg1 & (L1 == L1cc);
@@ -1505,8 +1523,373 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
 template <class real> NM_COLD void stage_constraint_pairs(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep) {
   stage_constraint_body<real, true>(sh, jrow, M, last, nosweep);
 }
+
+// =========================================================================================  stage C beyond kMaxCon contacts
+// Rare: a robot lying on the floor with folded legs can touch it with up to 28 hull vertices, and 15 tibia pairs can collide on
+// top of that; upstream keeps every contact (MuJoCo has no cap), so this path does too. It solves the SAME constraint set with the
+// SAME Gauss-Seidel / NoSlip updates in the SAME row order as the register-resident solver above, but matrix-free: row i lives in
+// slot i/64 of lane i%64 (kBigSlots rows per lane), and instead of a row of A = J M^-1 J' per lane the wave keeps the 24-vector
+// v = M^-1 J' f in LDS: residual_i = J_i.v + b_i, and a change d of f_i updates v by M^-1 J_i' d through the block factor
+// (legs on lanes 0..5 as in stage D). O(rows) state, ~0.1 us per row update; speed does not matter here, equality with upstream does.
+template <class real> struct BigRows {
+  V<real> Jb[kBigSlots][6], Jl[kBigSlots][3], Jm[kBigSlots][3], Rr[kBigSlots], bb[kBigSlots], f[kBigSlots], ARinv[kBigSlots], hA[kBigSlots];
+  V<real> invK1[kBigSlots], hK1[kBigSlots];
+  V<int> L[kBigSlots], L1[kBigSlots];
+  VB act[kBigSlots], small[kBigSlots];
+};
+// v (+)= M^-1 y for y = (yb[6] uniform base part, yl[3] per leg on lanes 0..5) through the block factor of M
+template <class real> NM_FN void big_minv(Sh<real>& sh, const real* yb, const V<real>* yl, bool accumulate) {
+  typedef V<real> vr;
+  const V<int> lane = opaque_lane();
+  const VB isleg = lane < kNLEG;
+  const V<int> leg = vmin(lane, V<int>(kNLEG - 1));
+  vr t[3], Mi[6], xb[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) Mi[j] = ldsv(sh.Minv, leg * 6 + j);
+  ldl3_solve(t, Mi, yl);
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vr wy = ldsv(sh.W, leg * 18 + j) * yl[0] + ldsv(sh.W, leg * 18 + (6 + j)) * yl[1] + ldsv(sh.W, leg * 18 + (12 + j)) * yl[2];
+    xb[j] = vr(yb[j] - lanesum6<real>(sel(isleg, wy, vr(real(0)))));
+  }
+  {
+    vr Lf[15], Di[6];
+#pragma unroll
+    for (int j = 0; j < 15; j++) Lf[j] = vr(sh.Lb[j]);
+#pragma unroll
+    for (int j = 0; j < 6; j++) Di[j] = vr(sh.Dbi[j]);
+    ldl6_solve(Lf, Di, xb);
+  }
+  vr x[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    x[k] = t[k];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[k] = x[k] - ldsv(sh.W, leg * 18 + (6 * k + j)) * xb[j];
+  }
+  wave_sync();
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vr nv = accumulate ? ldsv(sh.vv, V<int>(j)) + xb[j] : xb[j];
+    stsv(sh.vv, V<int>(j), nv, lane == 0);
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    vr nv = accumulate ? ldsv(sh.vv, leg * 3 + (6 + k)) + x[k] : x[k];
+    stsv(sh.vv, leg * 3 + (6 + k), nv, isleg);
+  }
+  wave_sync();
+}
+// v += M^-1 J' d for ONE row given by wave-uniform copies of its Jacobian (times d) and legs
+template <class real> NM_FN void big_update_v(Sh<real>& sh, const real* jb, const real* jl, const real* jm, int Li, int L1i) {
+  typedef V<real> vr;
+  const V<int> leg = vmin(opaque_lane(), V<int>(kNLEG - 1));
+  vr yl[3];
+#pragma unroll
+  for (int k = 0; k < 3; k++) yl[k] = sel(leg == Li, vr(jl[k]), vr(real(0))) + sel(leg == L1i, vr(jm[k]), vr(real(0)));
+  big_minv(sh, jb, yl, true);
+}
+template <class real> NM_FN V<real> big_residual(const Sh<real>& sh, const BigRows<real>& r, int k) {   // J_i . v + b_i (no R term)
+  V<real> g = r.bb[k];
+  const V<int> Lc = vmax(r.L[k], V<int>(0)), Lc1 = vmax(r.L1[k], V<int>(0));
+#pragma unroll
+  for (int j = 0; j < 6; j++) g += r.Jb[k][j] * sh.vv[j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) g += r.Jl[k][j] * ldsv(sh.vv, Lc * 3 + (6 + j)) + r.Jm[k][j] * ldsv(sh.vv, Lc1 * 3 + (6 + j));
+  return g;
+}
+template <class real> NM_FN void big_jtf(Sh<real>& sh, const BigRows<real>& r) {   // qfc = J' f
+  typedef V<real> vr;
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vr a = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < kBigSlots; k++) a += r.Jb[k][j] * r.f[k];
+    sh.qfc[j] = wsum<real>(a);
+  }
+  for (int l = 0; l < kNLEG; l++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      vr a = vr(real(0));
+#pragma unroll
+      for (int k = 0; k < kBigSlots; k++)
+        a += sel(r.L[k] == l, r.Jl[k][j] * r.f[k], vr(real(0))) + sel(r.L1[k] == l, r.Jm[k][j] * r.f[k], vr(real(0)));
+      sh.qfc[6 + 3 * l + j] = wsum<real>(a);
+    }
+  wave_sync();
+}
+template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Model<real>& M, bool last, bool nosweep) {
+  typedef V<real> vr;
+  const V<int> lane = opaque_lane();
+  const int ncon = uniform(sh.ncon), nefc = 4 * ncon;
+  BigRows<real> r;
+  const V<int> q4 = lane & 3;
+  const vr smu = sel((lane & 1) == 0, vr(M.mu), vr(-M.mu));
+  const VB even = (lane & 1) == 0;
+  // ---- rows: frame-axis Jacobians, pyramid rows, impedance / R / aref, diagonal of A and the pair coupling for NoSlip
+#pragma unroll
+  for (int k = 0; k < kBigSlots; k++) {
+    const V<int> row = lane + NM_WAVE * k;
+    const VB act = row < nefc;
+    const V<int> c = sel(act, row >> 2, V<int>(0));
+    vr cp[3] = {ldsv(sh.cpos(), c * 3), ldsv(sh.cpos(), c * 3 + 1), ldsv(sh.cpos(), c * 3 + 2)};
+    vr nrm[3] = {ldsv(sh.cnrm(), c * 3), ldsv(sh.cnrm(), c * 3 + 1), ldsv(sh.cnrm(), c * 3 + 2)};
+    const vr dist = ldsv(sh.cdist(), c);
+    const V<int> L = sel(act, ldsv(sh.cleg(), c), V<int>(-1)), L1 = sel(act, ldsv(sh.cleg1(), c), V<int>(-1));
+    const VB onleg = L >= 0, onleg1 = L1 >= 0;
+    const V<int> Lc = vmax(L, V<int>(0)), Lc1 = vmax(L1, V<int>(0));
+    vr e[3];
+    {  // mju_makeFrame
+      VB usey = (nrm[1] < vr(real(0.5))) & (nrm[1] > vr(real(-0.5)));
+      vr y0[3] = {vr(real(0)), sel(usey, vr(real(1)), vr(real(0))), sel(usey, vr(real(0)), vr(real(1)))};
+      vr dt = nrm[1] * y0[1] + nrm[2] * y0[2];
+      vr t1[3] = {y0[0] - dt * nrm[0], y0[1] - dt * nrm[1], y0[2] - dt * nrm[2]}, t2[3];
+      vr il = vr(real(1)) / vsqrt(t1[0] * t1[0] + t1[1] * t1[1] + t1[2] * t1[2]);
+      t1[0] = t1[0] * il; t1[1] = t1[1] * il; t1[2] = t1[2] * il;
+      cross3(t2, nrm, t1);
+#pragma unroll
+      for (int j = 0; j < 3; j++) e[j] = sel(q4 == 1, t1[j], sel(q4 == 2, t2[j], nrm[j]));
+    }
+    vr Fb[6], Fl[3], Fm[3];
+    {
+      vr m[3];
+      cross3(m, cp, e);
+      Fb[0] = e[0]; Fb[1] = e[1]; Fb[2] = e[2];
+#pragma unroll
+      for (int j = 0; j < 3; j++) Fb[3 + j] = sh.Rb[j] * m[0] + sh.Rb[3 + j] * m[1] + sh.Rb[6 + j] * m[2];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) {
+        vr a[3], rel[3], mm[3], a1[3], rel1[3], mm1[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          a[j] = ldsv(sh.axs, Lc * 9 + (3 * kk + j));
+          rel[j] = cp[j] - ldsv(sh.anc, Lc * 9 + (3 * kk + j));
+          a1[j] = ldsv(sh.axs, Lc1 * 9 + (3 * kk + j));
+          rel1[j] = cp[j] - ldsv(sh.anc, Lc1 * 9 + (3 * kk + j));
+        }
+        cross3(mm, rel, e);
+        cross3(mm1, rel1, e);
+        Fl[kk] = sel(onleg & act, dot3<vr>(a, mm), vr(real(0)));
+        Fm[kk] = sel(onleg1 & act, -dot3<vr>(a1, mm1), vr(real(0)));   // body1 side: -J(body1)
+      }
+#pragma unroll
+      for (int j = 0; j < 6; j++) Fb[j] = sel(act & !onleg1, Fb[j], vr(real(0)));   // base columns of J(b2) - J(b1) cancel
+    }
+    vr uF[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      uF[j] = Fb[j];
+#pragma unroll
+      for (int kk = 0; kk < 3; kk++) uF[j] = uF[j] - ldsv(sh.W, Lc * 18 + (6 * kk + j)) * Fl[kk] - ldsv(sh.W, Lc1 * 18 + (6 * kk + j)) * Fm[kk];
+    }
+    vr u[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      r.Jb[k][j] = quad<0x00>(Fb[j]) + smu * quad<0xA5>(Fb[j]);
+      u[j] = quad<0x00>(uF[j]) + smu * quad<0xA5>(uF[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      r.Jl[k][j] = quad<0x00>(Fl[j]) + smu * quad<0xA5>(Fl[j]);
+      r.Jm[k][j] = quad<0x00>(Fm[j]) + smu * quad<0xA5>(Fm[j]);
+    }
+    vr imp;
+    {
+      vr x = vabs(dist) / M.si_width;
+      vr ylo, yhi;
+      if (M.si_power == real(2)) {
+        vr omx = vmax(vr(real(1)) - x, vr(real(0)));
+        ylo = (x * x) / M.si_mid;
+        yhi = vr(real(1)) - (omx * omx) / (real(1) - M.si_mid);
+      } else {
+        ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
+        yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
+      }
+      vr y = sel(x <= vr(M.si_mid), ylo, yhi);
+      imp = M.si_d0 + y * (M.si_dmax - M.si_d0);
+      imp = sel(x >= vr(real(1)), vr(M.si_dmax), imp);
+      imp = sel(x <= vr(real(0)), vr(M.si_d0), imp);
+    }
+    vr invw = ldsv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
+    invw = invw + sel(onleg1, ldsv(M.colc, (Lc1 + 1) * kColN + 4), vr(real(0)));
+    const vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
+    vr vel = vr(real(0)), jas = vr(real(0)), jaw = vr(real(0));
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+      vel += r.Jb[k][j] * sh.qvel[j]; jas += r.Jb[k][j] * sh.qas[j]; jaw += r.Jb[k][j] * sh.warm[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      V<int> di = Lc * 3 + (6 + j), di1 = Lc1 * 3 + (6 + j);
+      vel += r.Jl[k][j] * ldsv(sh.qvel, di) + r.Jm[k][j] * ldsv(sh.qvel, di1);
+      jas += r.Jl[k][j] * ldsv(sh.qas, di) + r.Jm[k][j] * ldsv(sh.qas, di1);
+      jaw += r.Jl[k][j] * ldsv(sh.warm, di) + r.Jm[k][j] * ldsv(sh.warm, di1);
+    }
+    const vr aref = -M.solref_B * vel - M.solref_K * imp * dist;
+    vr t[3], t1m[3], xb[6];
+    {
+      vr Mi[6], Mi1[6];
+#pragma unroll
+      for (int j = 0; j < 6; j++) { Mi[j] = ldsv(sh.Minv, Lc * 6 + j); Mi1[j] = ldsv(sh.Minv, Lc1 * 6 + j); }
+      ldl3_solve(t, Mi, r.Jl[k]);
+      ldl3_solve(t1m, Mi1, r.Jm[k]);
+#pragma unroll
+      for (int j = 0; j < 6; j++) xb[j] = u[j];
+      ldl6_solve(sh.Lb, sh.Dbi, xb);
+    }
+    vr Ajj = r.Jl[k][0] * t[0] + r.Jl[k][1] * t[1] + r.Jl[k][2] * t[2] + (r.Jm[k][0] * t1m[0] + r.Jm[k][1] * t1m[1] + r.Jm[k][2] * t1m[2]);
+    vr Apq = r.Jl[k][0] * shfl_xor1(t[0]) + r.Jl[k][1] * shfl_xor1(t[1]) + r.Jl[k][2] * shfl_xor1(t[2]) +
+             (r.Jm[k][0] * shfl_xor1(t1m[0]) + r.Jm[k][1] * shfl_xor1(t1m[1]) + r.Jm[k][2] * shfl_xor1(t1m[2]));
+#pragma unroll
+    for (int j = 0; j < 6; j++) { Ajj += u[j] * xb[j]; Apq += u[j] * shfl_xor1(xb[j]); }
+    Apq = sel(even, Apq, shfl_xor1(Apq));   // the even row's copy of A[2p][2p+1] in both lanes of the pair
+    const vr K1 = Ajj + shfl_xor1(Ajj) - Apq - Apq;
+    r.small[k] = K1 < vr(real(1e-15));
+    r.invK1[k] = vr(real(1)) / K1;
+    r.hK1[k] = real(0.5) * K1;
+    const vr ARjj = Ajj + Rr;
+    r.ARinv[k] = sel(act, vr(real(1)) / ARjj, vr(real(0)));
+    r.hA[k] = real(0.5) * ARjj;
+    r.Rr[k] = Rr;
+    r.bb[k] = jas - aref;
+    r.L[k] = L; r.L1[k] = L1; r.act[k] = act;
+    const vr jar = jaw - aref;   // warm start (PGS branch of mj_fwdConstraint)
+    r.f[k] = sel(act & (jar < vr(real(0))), -(vr(real(1)) / Rr) * jar, vr(real(0)));
+  }
+  // ---- warm start: keep f only if its dual cost is below that of zero
+  {
+    big_jtf(sh, r);
+    const V<int> leg = vmin(lane, V<int>(kNLEG - 1));
+    vr yl[3] = {ldsv(sh.qfc, leg * 3 + 6), ldsv(sh.qfc, leg * 3 + 7), ldsv(sh.qfc, leg * 3 + 8)};
+    real yb[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) yb[j] = sh.qfc[j];
+    big_minv(sh, yb, yl, false);
+    vr cterm = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < kBigSlots; k++) {
+      const vr g = big_residual(sh, r, k);
+      cterm += sel(r.act[k], r.f[k] * (r.bb[k] + real(0.5) * (g - r.bb[k] + r.Rr[k] * r.f[k])), vr(real(0)));
+    }
+    if (wsum<real>(cterm) > real(0)) {
+#pragma unroll
+      for (int k = 0; k < kBigSlots; k++) r.f[k] = vr(real(0));
+      wave_sync();
+      stsv(sh.vv, sel(lane < 24, lane, V<int>(0)), real(0), lane < 24);
+      wave_sync();
+    }
+  }
+  // ---- mj_solPGS, row by row
+  for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
+    real improvement = real(0);
+#pragma unroll
+    for (int k = 0; k < kBigSlots; k++) {
+      for (int ln = 0; ln < NM_WAVE; ln++) {
+        if (NM_WAVE * k + ln >= nefc) break;
+        const vr res = big_residual(sh, r, k) + r.Rr[k] * r.f[k];
+        const vr dl = vmax(-res * r.ARinv[k], -r.f[k]);
+        const vr change = dl * (r.hA[k] * dl + res);
+        const real d = rdlane(dl, ln);
+        improvement -= rdlane(change, ln);
+        r.f[k] = sel(lane == ln, r.f[k] + dl, r.f[k]);
+        real jb[6], jl[3], jm[3];
+#pragma unroll
+        for (int j = 0; j < 6; j++) jb[j] = rdlane(r.Jb[k][j], ln) * d;
+#pragma unroll
+        for (int j = 0; j < 3; j++) { jl[j] = rdlane(r.Jl[k][j], ln) * d; jm[j] = rdlane(r.Jm[k][j], ln) * d; }
+        big_update_v(sh, jb, jl, jm, rdlane(r.L[k], ln), rdlane(r.L1[k], ln));
+      }
+    }
+    sh.it_pgs = iter + 1;
+    if (improvement * M.pgs_scale < M.pgs_tol) break;
+  }
+  // ---- mj_solNoSlip, pair by pair (the Newton form derived above)
+  for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
+    real improvement = real(0);
+    if (iter == 0) {
+      vr a = vr(real(0));
+#pragma unroll
+      for (int k = 0; k < kBigSlots; k++) a += sel(r.act[k], real(0.5) * r.f[k] * r.f[k] * r.Rr[k], vr(real(0)));
+      improvement = wsum<real>(a);
+    }
+#pragma unroll
+    for (int k = 0; k < kBigSlots; k++) {
+      for (int pp = 0; pp < NM_WAVE / 2; pp++) {
+        if (NM_WAVE * k + 2 * pp >= nefc) break;
+        const vr g = big_residual(sh, r, k);
+        const vr oq = shfl_xor1(r.f[k]), dg = g - shfl_xor1(g);
+        vr d = vmin(vmax(-dg * r.invK1[k], -r.f[k]), oq);
+        d = sel(r.small[k], real(0.5) * (oq - r.f[k]), d);
+        const vr change = d * (r.hK1[k] * d + dg);
+        const VB bad = change > vr(real(1e-10));
+        d = sel(bad, vr(real(0)), d);
+        const real d0 = rdlane(d, 2 * pp), d1 = rdlane(d, 2 * pp + 1);
+        improvement -= rdlane(sel(bad, vr(real(0)), change), 2 * pp);
+        r.f[k] = sel((lane >> 1) == pp, r.f[k] + d, r.f[k]);
+        real jb[6], jl[3], jm[3];
+#pragma unroll
+        for (int j = 0; j < 6; j++) jb[j] = rdlane(r.Jb[k][j], 2 * pp) * d0 + rdlane(r.Jb[k][j], 2 * pp + 1) * d1;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          jl[j] = rdlane(r.Jl[k][j], 2 * pp) * d0 + rdlane(r.Jl[k][j], 2 * pp + 1) * d1;
+          jm[j] = rdlane(r.Jm[k][j], 2 * pp) * d0 + rdlane(r.Jm[k][j], 2 * pp + 1) * d1;
+        }
+        big_update_v(sh, jb, jl, jm, rdlane(r.L[k], 2 * pp), rdlane(r.L1[k], 2 * pp));
+      }
+    }
+    sh.it_noslip = iter + 1;
+    if (improvement * M.pgs_scale < M.noslip_tol) break;
+  }
+  // ---- qfrc_constraint = J' f and the touch sensors
+  big_jtf(sh, r);
+  stsv(sh.efc_f, lane, r.f[0], lane < kMaxRow);
+  if (last) {
+    vr s_all[kNLEG], s_foot[kNLEG], s_base = vr(real(0));
+#pragma unroll
+    for (int l = 0; l < kNLEG; l++) { s_all[l] = vr(real(0)); s_foot[l] = vr(real(0)); }
+#pragma unroll
+    for (int k = 0; k < kBigSlots; k++) {
+      const V<int> row = lane + NM_WAVE * k;
+      const V<int> c = sel(r.act[k], row >> 2, V<int>(0));
+      vr cp[3] = {ldsv(sh.cpos(), c * 3), ldsv(sh.cpos(), c * 3 + 1), ldsv(sh.cpos(), c * 3 + 2)};
+      vr nrm[3] = {ldsv(sh.cnrm(), c * 3), ldsv(sh.cnrm(), c * 3 + 1), ldsv(sh.cnrm(), c * 3 + 2)};
+      vr nf = r.f[k] + shfl_xor1(r.f[k]);
+      nf = nf + shfl_xor2(nf);
+      auto foot_hit = [&](const V<int>& Lx, real sgn) {   // mju_rayGeom against the foot site sphere, as in the resident solver
+        vr ft[3], fr, sp[3], Rt[9];
+#pragma unroll
+        for (int j = 0; j < 3; j++) sp[j] = ldsv(M.footc, Lx * 4 + j);
+        fr = ldsv(M.footc, Lx * 4 + 3);
+#pragma unroll
+        for (int j = 0; j < 9; j++) Rt[j] = ldsv(sh.colR, (Lx + 1) * 9 + j);
+        matvec3(ft, Rt, sp);
+#pragma unroll
+        for (int j = 0; j < 3; j++) ft[j] = ft[j] + ldsv(sh.colp, (Lx + 1) * 3 + j);
+        vr dif[3] = {cp[0] - ft[0], cp[1] - ft[1], cp[2] - ft[2]};
+        vr b2 = sgn * (nrm[0] * dif[0] + nrm[1] * dif[1] + nrm[2] * dif[2]);
+        vr cc = dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2] - fr * fr;
+        vr det = b2 * b2 - cc;
+        vr sq = vsqrt(vmax(det, vr(real(0))));
+        return !(det < vr(real(1e-15))) & (((-b2 - sq) >= vr(real(0))) | ((-b2 + sq) >= vr(real(0))));
+      };
+      const VB hit = foot_hit(vmax(r.L[k], V<int>(0)), real(-1)), hit1 = foot_hit(vmax(r.L1[k], V<int>(0)), real(1));
+      const VB head = r.act[k] & ((lane & 3) == 0) & (nf > vr(real(0)));
+#pragma unroll
+      for (int l = 0; l < kNLEG; l++) {
+        s_all[l] += sel(head & ((r.L[k] == l) | (r.L1[k] == l)), nf, vr(real(0)));
+        s_foot[l] += sel(head & (((r.L[k] == l) & hit) | ((r.L1[k] == l) & hit1)), nf, vr(real(0)));
+      }
+      s_base += sel(head & (r.L[k] < 0), nf, vr(real(0)));
+    }
+#pragma unroll
+    for (int l = 0; l < kNLEG; l++) { sh.sens[l] = wsum<real>(s_all[l]); sh.sens[6 + l] = wsum<real>(s_foot[l]); }
+    sh.sens[12] = wsum<real>(s_base);
+  }
+  wave_sync();
+}
 template <class real> NM_FN void stage_constraint(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep = false) {
-  if (uniform(sh.anypair) != 0) stage_constraint_pairs<real>(sh, jrow, M, last, nosweep);
+  if (uniform(sh.ncon) > kMaxCon) stage_constraint_big<real>(sh, M, last, nosweep);
+  else if (uniform(sh.anypair) != 0) stage_constraint_pairs<real>(sh, jrow, M, last, nosweep);
   else stage_constraint_body<real, false>(sh, jrow, M, last, nosweep);
 }
 
@@ -1777,12 +2160,12 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     gstv(dbg, lane + 48, ldsv(sh.qfc, sel(lane < 24, lane, V<int>(0))), lane < 24);
     gstv(dbg, lane + 72, ldsv(sh.sens, sel(lane < 13, lane, V<int>(0))), lane < 13);
     gstv(dbg, lane + 88, ldsv(sh.cvb, sel(lane < 6, lane, V<int>(0))), lane < 6);
-    gstv(dbg, lane + 96, ldsv(sh.cdist, sel(lane < kMaxCon, lane, V<int>(0))), lane < kMaxCon);
-    gstv(dbg, lane + 112, ldsv(sh.cpos, sel(lane < 3 * kMaxCon, lane, V<int>(0))), lane < 3 * kMaxCon);
+    gstv(dbg, lane + 96, ldsv(sh.cdist(), sel(lane < kMaxCon, lane, V<int>(0))), lane < kMaxCon);
+    gstv(dbg, lane + 112, ldsv(sh.cpos(), sel(lane < 3 * kMaxCon, lane, V<int>(0))), lane < 3 * kMaxCon);
     gstv(dbg, V<int>(160), to_real<real>(sh.ncon), lane == 0);
     gstv(dbg, V<int>(161), to_real<real>(sh.nwarn), lane == 0);
     gstv(dbg, V<int>(162), to_real<real>(dropped), lane == 0);
-    gstv(dbg, lane + 165, ldsv(sh.cnrm, sel(lane < 6, lane, V<int>(0))), lane < 6);
+    gstv(dbg, lane + 165, ldsv(sh.cnrm(), sel(lane < 6, lane, V<int>(0))), lane < 6);
     gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
     gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
     gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);
@@ -1796,12 +2179,12 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #ifdef NM_EMUL
     A.stat_cnt[1] += dropped; A.stat_cnt[2] += sh.nwarn;
 #else
-    if (threadIdx.x == 0) { atomicAdd(A.stat_cnt + 1, dropped); atomicAdd(A.stat_cnt + 2, sh.nwarn); }
+    if (threadIdx.x == 0) { nm_consume(atomicAdd(A.stat_cnt + 1, dropped)); nm_consume(atomicAdd(A.stat_cnt + 2, sh.nwarn)); }
 #endif
   }
   if (A.stat_cnt && sh.nfallback) {
 #ifndef NM_EMUL
-    if (threadIdx.x == 0) atomicAdd(A.stat_cnt + 3, sh.nfallback);
+    if (threadIdx.x == 0) nm_consume(atomicAdd(A.stat_cnt + 3, sh.nfallback));
 #endif
   }
   if (A.physics_only) return;
@@ -1890,8 +2273,11 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     for (int k = 0; k < kNREW; k++) A.stat_sum[k] += epsum[0].v[k];
     A.stat_cnt[0] += 1;
 #else
-    if (threadIdx.x < kNREW) atomicAdd(A.stat_sum + threadIdx.x, epsum[0]);
-    if (threadIdx.x == 0) atomicAdd(A.stat_cnt, 1);
+    if (threadIdx.x < kNREW) nm_consume(atomicAdd(A.stat_sum + threadIdx.x, epsum[0]));
+    if (threadIdx.x == 0) {
+      nm_consume(atomicAdd(A.stat_cnt, 1));
+      if (time_out && A.to_list) nm_consume(atomicExch(A.to_list + atomicAdd(A.nto, 1), env));
+    }
 #endif
     epsum[0] = vr(real(0));
   }

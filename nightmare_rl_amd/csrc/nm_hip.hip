@@ -35,15 +35,11 @@ template <class real> __device__ __noinline__ void step_tail(const nm::Args<real
       const real s = __hip_atomic_load(A.stat_sum + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       A.ep_stats[lane] = (float)(s / (real)cnt / ep_len_s);
     }
-    if (A.time_outs) {   // [N] floats: 16 independent loads per lane in flight, then the stores
-      constexpr int kU = 16;
-      for (int base = 0; base < A.N; base += 64 * kU) {
-        float v[kU];
-#pragma unroll
-        for (int u = 0; u < kU; u++) { const int i = base + u * 64 + lane; v[u] = i < A.N ? A.timeout_now[i] : 0.f; }
-#pragma unroll
-        for (int u = 0; u < kU; u++) { const int i = base + u * 64 + lane; if (i < A.N) A.time_outs[i] = v[u]; }
-      }
+    if (A.time_outs) {   // all zeros, then ones at the envs on the time-out list (time-outs are a subset of the resets)
+      for (int i = lane; i < A.N; i += 64) A.time_outs[i] = 0.f;
+      const int n = __hip_atomic_load(A.nto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zeros have reached L2 before a one goes to the same address
+      for (int j = lane; j < n; j += 64) A.time_outs[__hip_atomic_load(A.to_list + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = 1.f;
     }
   }
   if (lane < nm::kNREW) A.stat_sum[lane] = real(0);
@@ -52,6 +48,7 @@ template <class real> __device__ __noinline__ void step_tail(const nm::Args<real
     A.counters[1] += __hip_atomic_load(A.stat_cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A.counters[2] += __hip_atomic_load(A.stat_cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A.stat_cnt[0] = 0; A.stat_cnt[1] = 0; A.stat_cnt[2] = 0; A.stat_cnt[3] = 0;
+    *A.nto = 0;
     *A.wave_done = 0;
   }
 }
@@ -72,14 +69,12 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   }
   nm::wave_step<real, G>(sh, Ms, As, wave);
   if (As.physics_only) return;
-  // The wave that finishes last closes the step (what used to be a second launch): every wave publishes its results
-  // (release fence), takes a ticket, and the holder of the last ticket sees all of them (acquire fence).
-  __threadfence();
+  // The wave that finishes last closes the step (what used to be a second launch). What it needs from the others went through
+  // device-scope atomics whose results each wave has already consumed (nm_consume), so the ticket needs no fence.
   int ticket = 0;
   if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done, 1);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
   if (ticket != (int)gridDim.x - 1) return;
-  __threadfence();
   step_tail<real>(As, Ms.ep_len_s);
 }
 
@@ -208,7 +203,7 @@ template <class real> struct Env : nm_env {
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
         dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * nm::kNREW) || dalloc(&A.feetair, n_ * nm::kNLEG) || dalloc(&A.feetflags, n_) ||
         dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, nm::kNREW) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
-        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, 1))
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, 1) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_))
       return 1;
     if (dalloc(&M_dev, 1)) return 1;
     HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));

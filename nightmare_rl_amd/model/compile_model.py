@@ -24,8 +24,11 @@ model class (third-party, not vendored by the reference; see SURVEY.md section 8
     and `stat.meaninertia` (mean diagonal of M at qpos0): engine_setconst.c `set0`.
 
 PARITY NOTE: MuJoCo is not installable here, so these tables are "parity unpinned" against
-a real `MjModel`; they are pinned by the known-answer tests in tests/test_model.py
-(total mass, symmetry, M positive-definite, exact-volume cross-check).
+a real `MjModel`; they are pinned by the known-answer tests in tests/test_model.py (the mesh-inertia
+rule on L-shaped prisms worked out by hand - star-convex: equals the exact solid; non-star-convex:
+the predicted over-count -, hull graphs of an icosahedron and a cube, body_invweight0 / meaninertia
+from finite-difference Jacobians) and tests/test_oracle_physics.py (total mass, symmetry,
+exact-volume cross-check, M against an independent CRBA).
 
 Usage:  python -m nightmare_rl_amd.model.compile_model /root/reference/models/nightmare_v3/mjmodel.xml
 """

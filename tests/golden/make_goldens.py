@@ -140,7 +140,7 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False, 
     rng = np.random.default_rng(seed + 1000)
     log = {k: [] for k in ("actions", "obs", "rew", "done", "time_outs", "commands", "ep_len", "cmd_u", "qpos", "qvel", "qacc_warmstart",
                            "base_lin_vel", "base_ang_vel", "projected_gravity", "tibia", "feet", "body", "dof_pos", "dof_vel",
-                           "episode_sums", "ep_stats", "nreset", "noise_u", "feet_air_time", "last_contacts", "last_contacts_filt", "base_heights")}
+                           "episode_sums", "ep_stats", "nreset", "noise_u", "feet_air_time", "last_contacts", "last_contacts_filt", "base_heights", "ncon")}
     # reset() = reset_idx(all) + step(zeros)   (env.py:392-396)
     with RandRecorder() as rr:
         env.reset_idx(np.arange(N))
@@ -194,6 +194,7 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False, 
         log["last_contacts"].append(np.array(env.last_contacts, np.uint8))
         log["last_contacts_filt"].append(np.array(env.last_contacts_filt, np.uint8))
         log["base_heights"].append(env.base_heights.copy())
+        log["ncon"].append(np.array([d._d.ncon for d in env.data]))       # contacts of the step's last forward pass (diagnostic)
         log["episode_sums"].append(np.stack([env.episode_sums[k].copy() for k in names]))
         if len(rst_ids):
             log["ep_stats"].append(np.array([float(extras["episode"]["rew_" + k]) for k in names]))
@@ -291,6 +292,58 @@ def _setup_mixed(env):
     env.commands[0:3] = 0.0
 
 
+def _many_contact_states(n_want=8, seed=1):
+    """Initial states from which a robot lying on folded legs shows more than 16 simultaneous contacts while its servos hold the
+    pose (found by simulating 256 random folded poses with the oracle; > 16 contacts is what the register-resident solver of the
+    HIP path cannot hold, so these exercise its matrix-free path)."""
+    rng = np.random.default_rng(seed)
+    N = 256
+    o = orc.OracleEnv(N, seed=seed, num_threads=8)
+    q = np.zeros((N, 25))
+    q[:, 2] = rng.uniform(0.08, 0.2, N)
+    for i in range(N):
+        ang = rng.uniform(0, 0.4)
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        q[i, 3] = np.cos(ang / 2)
+        q[i, 4:7] = np.sin(ang / 2) * ax
+        leg = [rng.uniform(-0.5, 0.5), rng.uniform(-1.5, -0.8), rng.uniform(0.3, 1.5)]
+        q[i, 7:] = np.tile(leg, 6) + rng.normal(size=18) * 0.05
+    o.set_state(q, np.zeros((N, 24)), np.zeros((N, 24)))
+    o.set_buffers(dof_pos=q[:, 7:])
+    default = np.tile([0, np.pi / 5, 0], 6)
+    count = np.zeros(N, int)
+    for t in range(80):
+        a = np.clip((o.get_buffers()["dof_pos"] + default) / 0.2, -5, 5).astype(np.float32)
+        o.step(a)
+        count += np.array([o.data(i).ncon for i in range(N)]) > 16
+    pick = np.argsort(-count, kind="stable")[:n_want]
+    assert (count[pick] > 0).sum() >= 4, count[pick]
+    return q[pick]
+
+
+def main_manycontacts():
+    """(h) more than 16 simultaneous contacts (robot lying on folded legs, servos holding the pose)."""
+    install_stub()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    q0 = _many_contact_states()
+    holder = {}
+
+    def setup(env):
+        holder["env"] = env
+        for i, d in enumerate(env.data):
+            d.qpos = q0[i]
+            d.qvel = np.zeros(24)
+        env.dof_pos[:] = q0[:, 7:]
+
+    def act(t, rng, N):
+        env = holder["env"]
+        return np.clip((env.dof_pos + env.default_dof_pos) / 0.2, -5, 5).astype(np.float32)
+
+    run_scenario("manycontacts", N=8, steps=80, seed=9, setup=setup, action_fn=act)
+
+
 def main_rewards():
     """(e) every reward function of the reference in the table (the scales config.py:88-96 keeps as comments), (f)/(g) contact
     modes 2 (terminate on tibia / body contact) and 0."""
@@ -330,5 +383,7 @@ if __name__ == "__main__":
         main_noise()
     elif len(sys.argv) > 1 and sys.argv[1] == "rewards":
         main_rewards()
+    elif len(sys.argv) > 1 and sys.argv[1] == "manycontacts":
+        main_manycontacts()
     else:
         main()

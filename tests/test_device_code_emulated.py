@@ -7,7 +7,8 @@ import pytest
 from conftest import load_golden
 
 SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz", "env_noise.npz",
-             "env_allrewards.npz", "env_modes22.npz", "env_modes01.npz"]   # every reward function in the table; contact modes 2 and 0
+             "env_allrewards.npz", "env_modes22.npz", "env_modes01.npz",    # every reward function in the table; contact modes 2 and 0
+             "env_manycontacts.npz"]                                       # more than 16 simultaneous contacts
 
 
 def teacher_forced(make_env, g, steps=None):

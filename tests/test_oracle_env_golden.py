@@ -6,7 +6,8 @@ import pytest
 from conftest import load_golden
 
 SCENARIOS = ["env_reset_rollout.npz", "env_timeouts.npz", "env_falls.npz", "env_noise.npz",
-             "env_allrewards.npz", "env_modes22.npz", "env_modes01.npz"]   # every reward function in the table; contact modes 2 and 0
+             "env_allrewards.npz", "env_modes22.npz", "env_modes01.npz",    # every reward function in the table; contact modes 2 and 0
+             "env_manycontacts.npz"]                                       # more than 16 simultaneous contacts
 
 
 def golden_config(g):
@@ -110,6 +111,11 @@ def test_reward_fixtures_exercise_every_function_and_mode():
     assert only_mode2.sum() >= 2
     z = load_golden("env_modes01.npz")
     assert "tracking_ang_vel" not in [str(n) for n in z["reward_names"]] and "dof_vel" in [str(n) for n in z["reward_names"]]
+
+
+def test_many_contact_fixture_exceeds_the_resident_solver():
+    g = load_golden("env_manycontacts.npz")
+    assert (g["ncon"] > 16).sum() >= 10 and g["ncon"].max() >= 20     # 16 = rows the register-resident solver of the HIP path holds / 4
 
 
 def test_golden_covers_edge_cases():
