@@ -38,48 +38,32 @@ def host_cores():
     return max(1, min(n, 16)) if n > 64 else n   # no quota visible on a >64-thread host: stay within the documented 16-CPU share
 
 
-def cpu_baseline(seconds_budget=15.0):
-    """The CPU oracle (a port: MuJoCo itself is not installable) on this box's host cores, bounded sample."""
+def _time_oracle(n, threads, seconds):
     from oracle import oracle as orc
-    cores = host_cores()
-    n = 1024
-    env = orc.OracleEnv(n, seed=0, num_threads=cores)
+    env = orc.OracleEnv(n, seed=0, num_threads=threads)
     env.reset()
     rng = np.random.default_rng(0)
     acts = [rng.uniform(-1, 1, (n, 18)).astype(np.float32) for _ in range(8)]
-    for i in range(10):
+    for i in range(3):
         env.step(acts[i % 8])
     t0 = time.perf_counter()
     k = 0
-    while time.perf_counter() - t0 < seconds_budget:
+    while time.perf_counter() - t0 < seconds:
         env.step(acts[k % 8])
         k += 1
-    dt = time.perf_counter() - t0
-    return {"value": n * k / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {k} random-action steps from reset (fp64 C restatement of mj_step + env epilogue, OpenMP over envs)"}
+    return n * k / (time.perf_counter() - t0), k
 
 
-def cpu_baseline_detail(seconds_each=6.0):
-    """the CPU path at T = 1 and T = all cores, N = 1 and N = 4096 (the reference's own case is N = 1, T = 1)."""
-    from oracle import oracle as orc
-    out = {}
-    for n in (1, 4096):
-        for threads in (1, host_cores()):
-            if n == 1 and threads > 1:
-                continue
-            env = orc.OracleEnv(n, seed=0, num_threads=threads)
-            env.reset()
-            rng = np.random.default_rng(0)
-            acts = [rng.uniform(-1, 1, (n, 18)).astype(np.float32) for _ in range(8)]
-            for i in range(3):
-                env.step(acts[i % 8])
-            t0 = time.perf_counter()
-            k = 0
-            while time.perf_counter() - t0 < seconds_each:
-                env.step(acts[k % 8])
-                k += 1
-            out[f"N{n}_T{threads}"] = n * k / (time.perf_counter() - t0)
-    return out
+def cpu_baseline(envs=4096):
+    """The CPU oracle (a port: MuJoCo itself is not installable) on this box's host cores: the same workload (N envs, random
+    actions, full step()) on a bounded sample, plus the grid SURVEY 8(d) asks for - N in {1, N} x T in {1, all cores}. It is a C
+    restatement with no Python in the loop, i.e. an upper bound for the reference's own MuJoCo + numpy path. ~20 s in total."""
+    cores = host_cores()
+    v_all, k = _time_oracle(envs, cores, 10.0)
+    grid = {f"N{envs}_T{cores}": v_all, "N1_T1": _time_oracle(1, 1, 3.0)[0], f"N{envs}_T1": _time_oracle(envs, 1, 5.0)[0]}
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{envs} envs x {k} random-action steps from reset (fp64 C restatement of mj_step + env epilogue, OpenMP over envs)",
+            "grid_env_steps_per_s": grid}
 
 
 def main():
@@ -89,7 +73,6 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-detail", action="store_true", help="also time the CPU oracle at N in {1, 4096} x T in {1, all cores} (adds ~20 s)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -137,13 +120,18 @@ def main():
     gathered = torch.zeros(world * E, device=dev) if world > 1 else None
     horizon = 80
 
-    def one_step(i):
-        nonlocal returns, gathered
+    ncoll = 0
+
+    def one_step(i, last=False):
+        nonlocal returns, gathered, ncoll
         _, _, rew, done, _ = env.step(acts[i % pool])
         returns += rew
-        if (i + 1) % horizon == 0 and world > 1:     # PPO-update boundary: one all-gather of per-env returns over xGMI
+        # PPO-update boundary: one all-gather of per-env returns over xGMI, every `horizon` steps and at the end of the run (so a
+        # short timed region still contains the collective)
+        if ((i + 1) % horizon == 0 or last) and world > 1:
             gathered = gather_returns(returns, total_envs=world * E)
             returns.zero_()
+            ncoll += 1
 
     def sync():
         if world > 1:
@@ -151,11 +139,12 @@ def main():
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
-        one_step(i)
+        one_step(i, last=i == args.warmup - 1)
     sync()
+    ncoll = 0
     t0 = time.perf_counter()
     for i in range(args.steps):
-        one_step(args.warmup + i)
+        one_step(args.warmup + i, last=i == args.steps - 1)
     sync()
     dt = time.perf_counter() - t0
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -173,12 +162,16 @@ def main():
         k_ms, k_n = env.profile(False)
         k_avg = k_ms / max(k_n, 1) * 1e-3
         achieved = B_FULL * E / k_avg / 1e9
-        traffic = None   # HBM-side bytes per launch from the committed rocprofv3 PMC passes of this kernel (profiles/)
+        # HBM-side bytes per launch and VALU issue utilisation are NOT measured by this process: they come from the committed
+        # rocprofv3 --pmc passes of this same command (separate runs, as the counter guide prescribes); null when there are none
+        traffic = valu = None
+        pmc_file = os.path.join("profiles", "r02_pmc_step_kernel.json")
         try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))
-            traffic = tj["bytes_per_launch"] * (E / 4096.0)
+            tj = json.load(open(os.path.join(ROOT, pmc_file)))
+            traffic = tj["hbm_bytes_per_launch"] * (E / 4096.0)
+            valu = tj.get("valu")
         except Exception:
-            pass
+            pmc_file = None
         # physics-only (BASELINE config 2) and step + 2x256 MLP policy forward (config 3), for DESIGN.md / the log
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -207,6 +200,20 @@ def main():
             graph.replay()
         torch.cuda.synchronize(dev)
         closed = E * 300 / (time.perf_counter() - t1)
+        # the fp64 verification build of the same kernel (what the exact-parity tests run)
+        cfg64 = NightmareV3Config()
+        cfg64.env.num_envs = E
+        env64 = NightmareV3Env(cfg64, device=dev, seed=0, dtype=torch.float64)
+        env64.reset()
+        for i in range(5):
+            env64.step(acts[i % pool])
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        for i in range(40):
+            env64.step(acts[i % pool])
+        torch.cuda.synchronize(dev)
+        f64 = E * 40 / (time.perf_counter() - t1)
+        env64.close()
         out = {
             "metric": "env-steps/sec at N parallel Nightmare-v3 envs, 1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,19 +221,22 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{E} Nightmare-v3 envs per GPU, random-action rollout U(-1,1)^18, full step(): 2 x 8 ms substeps "
                                    "(18-DoF dynamics + floor contact, PGS x3 + noslip x4) + obs/reward/termination/reset",
-                       "envs_per_gpu": E, "decimation": 2, "sharding": f"dp{world} by env id, all-gather of returns every {horizon} steps"},
+                       "envs_per_gpu": E, "decimation": 2,
+                       "sharding": f"dp{world} by env id, all-gather of returns every {horizon} steps and on the last timed step"},
+            "collectives_timed": ncoll,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6,
+                         "traffic": traffic, "traffic_source": pmc_file and f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)",
+                         "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6,
                          "algorithmic_bytes_per_env_step": B_FULL,
+                         "valu": valu,
                          "note": "latency/VALU-issue bound, not HBM bound: see DESIGN.md"},
             "physics_only_env_steps_per_s": phys,
             "closed_loop_mlp_2x256_env_steps_per_s": closed,
+            "fp64_verification_kernel_env_steps_per_s": f64,
             "counters": env.counters(),
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline()
-            if args.cpu_detail:
-                out["cpu_baseline"]["detail_env_steps_per_s"] = cpu_baseline_detail()
+            out["cpu_baseline"] = cpu_baseline(E)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -123,7 +123,7 @@ class RandRecorder:
         np.random.rand = self._orig
 
 
-def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False, cfg_fn=None):
+def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False, cfg_fn=None, post_fn=None):
     import torch
     from envs.nightmare_v3_config import NightmareV3Config
     from envs.nightmare_v3_env import NightmareV3Env
@@ -217,6 +217,8 @@ def run_scenario(name, N, steps, seed, setup=None, action_fn=None, noise=False, 
                                  cfg.env.body_max_contact_force, cfg.rewards.base_height_target, cfg.rewards.max_contact_force], dtype=np.float64)
     for k, v in init.items():
         out["init_" + k] = v
+    if post_fn is not None:
+        post_fn(env, out)
     path = os.path.join(ROOT, "tests", "golden", f"env_{name}.npz")
     np.savez_compressed(path, **out)
     print(name, "steps", steps, "N", N, "resets", int(out["nreset"].sum()), "timeouts", int(out["time_outs"].sum()),
@@ -344,6 +346,51 @@ def main_manycontacts():
     run_scenario("manycontacts", N=8, steps=80, seed=9, setup=setup, action_fn=act)
 
 
+def main_statelog():
+    """(i) cfg.viewer.record_states (env.py:261-272): the pickle the reference class writes when env 0 resets, stored as arrays
+    (time, qpos, qvel, act of every record), plus class_to_dict of both reference config classes as JSON (helpers.py:3-18)."""
+    import glob
+    import json
+    import pickle
+    import shutil
+    install_stub()
+    sys.path.insert(0, REF)
+    os.chdir(REF)
+    shutil.rmtree("/tmp/nm_golden_logs", ignore_errors=True)
+
+    def cfg_fn(cfg):
+        cfg.viewer.record_states = True
+
+    def setup(env):
+        import torch
+        env.episode_length_buf = torch.tensor([1238, 300], dtype=torch.int64)
+
+    def post(env, out):
+        files = sorted(glob.glob("/tmp/nm_golden_logs/*.pkl"))
+        assert len(files) == 1, files
+        with open(files[0], "rb") as f:
+            rec = pickle.load(f)
+        assert isinstance(rec, list) and all(isinstance(r, tuple) and len(r) == 4 for r in rec)
+        out["log_time"] = np.array([r[0] for r in rec])
+        out["log_qpos"] = np.stack([r[1] for r in rec])
+        out["log_qvel"] = np.stack([r[2] for r in rec])
+        out["log_act_size"] = np.array([np.asarray(r[3]).size for r in rec])
+        out["log_types"] = np.array([type(rec).__name__, type(rec[0]).__name__, type(rec[0][0]).__name__, type(rec[0][1]).__name__,
+                                     str(rec[0][1].dtype), str(rec[0][1].shape), str(rec[0][2].shape), str(np.asarray(rec[0][3]).shape)])
+        pend = env.recorded_states           # what has been logged since the dump (the next file's beginning)
+        out["pending_time"] = np.array([r[0] for r in pend])
+        out["pending_qpos"] = np.stack([r[1] for r in pend])
+
+    run_scenario("statelog", N=2, steps=20, seed=10, setup=setup, cfg_fn=cfg_fn, post_fn=post,
+                 action_fn=lambda t, rng, N: rng.uniform(-1, 1, (N, 18)).astype(np.float32))
+    from envs.helpers import class_to_dict
+    from envs.nightmare_v3_config import NightmareV3Config, NightmareV3ConfigPPO
+    dump = {"NightmareV3Config": class_to_dict(NightmareV3Config()), "NightmareV3ConfigPPO": class_to_dict(NightmareV3ConfigPPO())}
+    with open(os.path.join(ROOT, "tests", "golden", "config_class_to_dict.json"), "w") as f:
+        json.dump(dump, f, indent=1, sort_keys=False)
+    print("config_class_to_dict.json", {k: len(v) for k, v in dump.items()})
+
+
 def main_rewards():
     """(e) every reward function of the reference in the table (the scales config.py:88-96 keeps as comments), (f)/(g) contact
     modes 2 (terminate on tibia / body contact) and 0."""
@@ -385,5 +432,7 @@ if __name__ == "__main__":
         main_rewards()
     elif len(sys.argv) > 1 and sys.argv[1] == "manycontacts":
         main_manycontacts()
+    elif len(sys.argv) > 1 and sys.argv[1] == "statelog":
+        main_statelog()
     else:
         main()

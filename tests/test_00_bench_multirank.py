@@ -1,0 +1,30 @@
+"""bench.py's N>1 path rehearsed on the one-GPU box: two ranks (gloo; both share the card) launched the way the driver launches
+them, `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --steps 20 --warmup 5`. The JSON line must report a
+whole-job value for 2 x E envs and at least one all-gather INSIDE the timed region (with the driver's --steps 20 the every-80-steps
+boundary alone would never fire). Named test_00_* so that it runs before anything in this pytest process has touched the GPU: the
+ranks are started as child processes."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_rank_bench_times_a_collective():
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29531", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5",
+           "--envs-per-gpu", "1024"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["scaling"] == "weak"
+    assert out["collectives_timed"] >= 1
+    assert out["config"]["envs_per_gpu"] == 1024
+    assert abs(out["value"] - 2 * 1024 * 20 / (out["ms_per_step"] * 20 / 1e3)) < 1e-6 * out["value"]   # whole-job aggregate
+    assert "cpu_baseline" not in out                                                                    # rank 0 at N=1 only

@@ -86,6 +86,36 @@ def test_config_tree_matches_reference_surface():
     assert t["runner"]["num_steps_per_env"] == 80 and t["seed"] == 1
 
 
+def test_class_to_dict_matches_the_reference_dump():
+    """tests/golden/config_class_to_dict.json = class_to_dict(...) of the reference's own config classes (train.py:37 hands it to the
+    runner; env.py:80 builds the reward table from it): same nesting, same keys in the same (dir) order, same values - except the
+    three defaults this backend changes on purpose (device, viewer.render, viewer.record_states)."""
+    import json
+    from nightmare_rl_amd.envs.helpers import class_to_dict
+    from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config, NightmareV3ConfigPPO
+    ref = json.load(open(os.path.join(ROOT, "tests", "golden", "config_class_to_dict.json")))
+    ours = {"NightmareV3Config": class_to_dict(NightmareV3Config()), "NightmareV3ConfigPPO": class_to_dict(NightmareV3ConfigPPO())}
+    assert ours["NightmareV3Config"].pop("device") == "cuda" and ref["NightmareV3Config"].pop("device") == "cpu"
+    assert ours["NightmareV3Config"]["viewer"] == {"record_states": False, "render": False}
+    assert ref["NightmareV3Config"]["viewer"] == {"record_states": True, "render": True}
+    ours["NightmareV3Config"]["viewer"] = ref["NightmareV3Config"]["viewer"]
+
+    def same(a, b, path=""):
+        assert type(a) is type(b) or (isinstance(a, (int, float)) and isinstance(b, (int, float))), (path, a, b)
+        if isinstance(a, dict):
+            assert list(a) == list(b), (path, list(a), list(b))      # key order matters: it is the reward evaluation order
+            for k in a:
+                same(a[k], b[k], path + "." + k)
+        elif isinstance(a, list):
+            assert len(a) == len(b), path
+            for i, (x, y) in enumerate(zip(a, b)):
+                same(x, y, f"{path}[{i}]")
+        else:
+            assert a == b, (path, a, b)
+
+    same(ours, ref)
+
+
 def test_golden_config_agrees_with_goldens():
     """reward scale * dt and episode constants the reference computed at construction (fixtures) vs host constants."""
     from conftest import load_golden

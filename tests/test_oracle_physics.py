@@ -202,3 +202,169 @@ def test_bad_state_resets_like_mujoco(oracle_mod):
     p.qvel[0] = np.nan
     p.step(1)
     assert p.nwarning == 1 and np.isfinite(p.qpos).all() and abs(p.qpos[2] - (0.15 - G * 0.008**2)) < 1e-12
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+# Known answers for the stages that were only checked for self-consistency: contact impedance / regulariser / reference
+# acceleration (P6), the PGS and NoSlip update rules (P7), the 7 mm foot-site touch test (P8).
+MU = 1.0                      # default geom friction (no friction attribute in mjmodel.xml)
+SOLREF = (0.02, 1.0)          # MuJoCo defaults: time constant, damping ratio
+SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
+
+
+def feet_down(p, z):
+    p.reset()
+    p.qpos[7:] = np.tile([0.0, -0.9, 0.6], 6)
+    p.qpos[2] = z
+    p.qvel[:] = 0
+
+
+def touch_height(p):
+    """Base height at which the lowest foot of the feet_down pose touches the plane."""
+    feet_down(p, 0.3)
+    p.forward()
+    low = []
+    for g in range(1, 7):                                   # lowest hull vertex of each tibia at this pose
+        b = int(T["col_body"][g])
+        V = T["hull_vert"][int(T["col_vadr"][g]):int(T["col_vadr"][g]) + int(T["col_nvert"][g])]
+        low.append((p.xpos[b][2] + V @ p.xmat[b].reshape(3, 3)[2]).min())
+    return 0.3 - min(low)
+
+
+def test_contact_impedance_regulariser_and_reference_acceleration_by_hand(oracle_mod):
+    """One foot 0.25 mm into the floor, the robot moving straight down at 0.1 m/s. By hand, from MuJoCo's documented formulas with
+    solref (0.02, 1), solimp (0.9, 0.95, 0.001, 0.5, 2), mu = 1:
+       x = 0.25: imp = 0.9 + 0.05 * x^2 / 0.5 = 0.90625                 k = 1 / (0.95^2 0.02^2) = 2770.0831   b = 2 / (0.95 0.02) = 105.26316
+       pyramid rows: vel = n.v +- mu t.v = -0.1;   aref = -b vel - k imp dist = 10.526316 + 0.627597 = 11.153913
+       R = 2 mu^2 (1 - imp)/imp * invweight0 (1 + mu^2) = 4 (0.09375 / 0.90625) invweight0[tibia]"""
+    p = oracle_mod.Physics()
+    assert tuple(T["solref"]) == SOLREF and tuple(T["solimp"]) == SOLIMP and float(T["friction"]) == MU
+    z0 = touch_height(p)
+    feet_down(p, z0 - 0.00025)                              # the lowest foot ends up 0.25 mm below the plane
+    p.qvel[2] = -0.1
+    p.forward()
+    c = int(np.argmin(p.con_dist[: p.ncon]))
+    assert abs(p.con_dist[c] + 0.00025) < 1e-12 and p.con_body1[c] == 0
+    rows = slice(4 * c, 4 * c + 4)
+    np.testing.assert_allclose(p.efc("imp")[rows], 0.90625, atol=1e-9)
+    np.testing.assert_allclose(p.efc("K")[rows], 2770.0831, rtol=1e-7)
+    np.testing.assert_allclose(p.efc("B")[rows], 105.26316, rtol=1e-7)
+    np.testing.assert_allclose(p.efc("vel")[rows], -0.1, atol=1e-12)
+    np.testing.assert_allclose(p.efc("aref")[rows], 11.153913, rtol=1e-7)
+    invw = T["body_invweight0"][p.con_body[c]][0]
+    np.testing.assert_allclose(p.efc("R")[rows], 4 * (0.09375 / 0.90625) * invw, rtol=1e-9)
+    np.testing.assert_allclose(p.efc("D")[rows] * p.efc("R")[rows], 1.0, rtol=1e-12)
+    # the other two branches of the impedance curve: upper half (x = 0.75 -> y = 1 - 0.25^2/0.5 = 0.875) and saturation (x >= 1)
+    for depth, imp in ((0.00075, 0.9 + 0.05 * 0.875), (0.002, 0.95)):
+        feet_down(p, z0 - depth)
+        p.forward()
+        c = int(np.argmin(p.con_dist[: p.ncon]))
+        np.testing.assert_allclose(p.efc("imp")[4 * c], imp, atol=1e-9)
+
+
+def pgs_noslip_numpy(AR, R, b, f0, iters, noslip_iters, scale, tol, noslip_tol):
+    """MuJoCo's dual solvers as its documentation describes them, written independently of the oracle's C: projected Gauss-Seidel on
+    0.5 f'AR f + f'b, f >= 0; then, for each opposing pair of pyramid edges, the exact 1-D minimisation of the UNregularised cost
+    along (f0 - f1) with f0 + f1 fixed and both kept non-negative."""
+    n = len(b)
+    f = f0.copy()
+    for _ in range(iters):
+        imp = 0.0
+        for i in range(n):
+            res = AR[i] @ f + b[i]
+            new = max(0.0, f[i] - res / AR[i, i])
+            d = new - f[i]
+            imp -= 0.5 * d * d * AR[i, i] + d * res
+            f[i] = new
+        if imp * scale < tol:
+            break
+    A = AR - np.diag(R)
+    for it in range(noslip_iters):
+        imp = 0.5 * (f * f * R).sum() if it == 0 else 0.0
+        for j in range(0, n, 2):
+            s = f[j] + f[j + 1]
+            g = A @ f + b                                   # gradient of the unregularised cost
+            K1 = A[j, j] + A[j + 1, j + 1] - 2 * A[j, j + 1]
+            y = (f[j] - f[j + 1]) / 2 - (g[j] - g[j + 1]) / K1 if K1 > 1e-15 else 0.0    # Newton step on the 1-D quadratic: slope g0 - g1, curvature K1
+            y = min(max(y, -s / 2), s / 2)
+            new = np.array([s / 2 + y, s / 2 - y])
+            d = new - f[j:j + 2]
+            imp -= 0.5 * d @ A[j:j + 2, j:j + 2] @ d + d @ g[j:j + 2]
+            f[j:j + 2] = new
+        if imp * scale < noslip_tol:
+            break
+    return f
+
+
+def test_pgs_and_noslip_against_an_independent_numpy_solver(oracle_mod):
+    p = oracle_mod.Physics()
+    rng = np.random.default_rng(11)
+    scale = 1.0 / (float(T["meaninertia"]) * 24)
+    seen = 0
+    z0 = touch_height(p)
+    for trial in range(12):
+        feet_down(p, z0 - rng.uniform(0.0005, 0.004))
+        p.qpos[7:] += rng.uniform(-0.05, 0.05, 18)
+        p.qvel[:] = rng.normal(size=24) * 0.4
+        p.qacc_warmstart[:] = rng.normal(size=24) * (trial % 3)          # zero, moderate and poor warm starts
+        p.forward()
+        n = p.nefc
+        if n == 0:
+            continue
+        seen += 1
+        AR, R, b, D, aref, J = p.efc("AR"), p.efc("R"), p.efc("b"), p.efc("D"), p.efc("aref"), p.s.np("J")[:n]
+        jar = J @ p.qacc_warmstart - aref
+        f0 = np.where(jar < 0, -D * jar, 0.0)
+        if f0 @ b + 0.5 * f0 @ AR @ f0 > 0:
+            f0[:] = 0
+        f = pgs_noslip_numpy(AR, R, b, f0, int(T["iterations"]), int(T["noslip_iterations"]), scale, float(T["tolerance"]), float(T["noslip_tolerance"]))
+        np.testing.assert_allclose(p.efc_force[:n], f, rtol=1e-9, atol=1e-9)
+        # run to convergence without NoSlip: the fixed point of the PGS rule is the solution of the dual LCP
+        fc = pgs_noslip_numpy(AR, R, b, f0, 20000, 0, scale, 0.0, 0.0)
+        w = AR @ fc + b
+        assert (fc >= 0).all() and (w > -1e-6 * np.abs(b).max()).all() and abs(fc @ w) < 1e-6 * (np.abs(b).max() ** 2)
+    assert seen >= 8
+
+
+def test_foot_touch_sensor_sees_only_contacts_inside_the_7mm_sphere(oracle_mod):
+    """P8 (mjmodel.xml:49...): a touch sensor adds a contact's normal force when the ray from the contact point along the normal
+    (towards the sensor's body) hits the site sphere. With the floor below the foot that is: the contact point lies inside the
+    7 mm sphere, or under it within its horizontal radius. Independent classification with plain geometry; the tibia sites
+    (10 m spheres) see every contact of the body."""
+    p = oracle_mod.Physics()
+    rng = np.random.default_rng(12)
+    hits = misses = 0
+    z0 = touch_height(p)
+    for trial in range(60):
+        feet_down(p, z0 - rng.uniform(0.0, 0.02))
+        p.qpos[7:] += rng.uniform(-0.5, 0.5, 18)
+        ang = rng.uniform(0, 0.25)
+        ax = rng.normal(size=3)
+        ax /= np.linalg.norm(ax)
+        p.qpos[3:7] = np.r_[np.cos(ang / 2), np.sin(ang / 2) * ax]
+        p.forward()
+        foot_expect, tibia_expect = np.zeros(6), np.zeros(6)
+        for c in range(p.ncon):
+            b = int(p.con_body[c])
+            if b < 2 or (b - 2) % 3 != 2 or p.con_body1[c] != 0:
+                continue
+            leg = (b - 2) // 3
+            nf = p.efc_force[4 * c: 4 * c + 4].sum()
+            if nf <= 0:
+                continue
+            tibia_expect[leg] += nf
+            site = p.xpos[b] + p.xmat[b].reshape(3, 3) @ T["sens_pos"][6 + leg]
+            r = float(T["sens_radius"][6 + leg])
+            assert abs(r - 0.007) < 1e-12
+            d = p.con_pos[c] - site
+            horiz = np.hypot(d[0], d[1])
+            inside = np.linalg.norm(d) < r
+            below_within = d[2] > 0 and horiz < r          # ray points down (-z): it can only reach a sphere that lies below the point
+            if inside or below_within:
+                foot_expect[leg] += nf
+                hits += 1
+            else:
+                misses += 1
+        np.testing.assert_allclose(p.sensordata[6:12], foot_expect, atol=1e-9)
+        np.testing.assert_allclose(p.sensordata[0:6], tibia_expect, atol=1e-9)
+    assert hits >= 20 and misses >= 20                      # both outcomes are exercised
