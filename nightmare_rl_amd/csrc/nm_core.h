@@ -99,7 +99,8 @@ template <class real> struct Args {
   real* stat_sum;        // [kNREW] sums of episode sums over envs that reset this step
   int* stat_cnt;         // [4]: #resets this step, #contacts dropped (contact cap), #bad-state resets (mj_check*), #hull-search fallbacks
   // end of step, done by whichever wave finishes last (device build): extras refreshed only when >= 1 env reset (env.py:344-371)
-  int* wave_done;        // [1] waves that have published their results in this launch
+  int* wave_done;        // tickets of the waves that have published their results in this launch: [g*32] per group of 64 waves,
+                         // [kTicketTop] over the groups (one counter for 2048 waves serialises ~25 us of same-address atomics)
   int *nto, *to_list;    // [1], [N]: envs that timed out in this launch (what the closing wave turns into extras['time_outs'])
   float *ep_stats, *time_outs;   // [kNREW] extras['episode'], [N] extras['time_outs']
   long long* counters;   // [3] running totals of stat_cnt[1..3]
@@ -115,6 +116,7 @@ template <class real> struct Args {
   real* rec;
   int rec_env;
 };
+constexpr int kTicketGroup = 64, kTicketStride = 32, kTicketTop = 0;   // group g's counter at [(g + 1) * kTicketStride] (own 128 B line)
 constexpr uint64_t kNoiseKey = 0x4E4F495345ull;
 constexpr int kDbgN = 256;
 
@@ -145,13 +147,15 @@ template <class real> struct Sh {
   real dbg_b[kMaxRow], dbg_a[kMaxRow], dbg_f0[kMaxRow];
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
-  int nfallback, nhop;
+  int nhop;
   real eact[kNU], epact[kNU], epdv[kNU];  // this step's clipped actions, last step's actions and joint velocities (epilogue inputs)
   real ecmd[4], eepsum[kNREW];    // env buffers fetched at load time for the epilogue: commands, episode sums
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
   unsigned ectr;                  // command RNG counter
   int cstart[8], ccnt[8];         // contacts of colliding mesh g (0 = base, 1..6 = tibias): first index and count (floor contacts)
-  int hcache[8];                  // support vertex of each colliding mesh found last time (warm start of the hull search)
+  int hcache[8];                  // [0..6] support vertex of each colliding mesh found last time (warm start of the hull search);
+                                  // [7] running count of this env's exhaustive-scan fallbacks (a tuning diagnostic that travels with the
+                                  // row: 2048 waves adding to ONE counter serialise at ~12 ns each and hold the kernel's end back)
 };
 
 static_assert(kNLEG * 66 >= 9 * kMaxConBig, "contact list must fit the leg staging area");
@@ -311,6 +315,9 @@ template <class T> NM_FN void nm_consume(T x) { asm volatile("" ::"v"(x) : "memo
 __device__ unsigned long long g_stamps[16];
 NM_FN void nm_stamp(int k) {   // k = -1 starts the clock, k = 10 is the last stamp of a wave and flushes its sums
   __shared__ unsigned long long tl, acc[16];
+#ifdef NM_STAMPS_B
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // exact attribution: outstanding loads belong to the segment that issued them
+#endif
   unsigned long long n = __builtin_amdgcn_s_memtime();
   if (threadIdx.x == 0) {
     if (k < 0) for (int i = 0; i < 16; i++) acc[i] = 0;
@@ -321,6 +328,14 @@ NM_FN void nm_stamp(int k) {   // k = -1 starts the clock, k = 10 is the last st
 }
 #else
 NM_FN void nm_stamp(int) {}
+#endif
+// -DNM_STAMPS_B: slots 11..13 time the sub-phases of the floor collision instead of the epilogue segments
+#ifdef NM_STAMPS_B
+#define NM_ESTAMP(k)
+#define NM_BSTAMP(k) nm_stamp(k)
+#else
+#define NM_ESTAMP(k) nm_stamp(k)
+#define NM_BSTAMP(k)
 #endif
 
 // =========================================================================================  stage A
@@ -1019,6 +1034,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     val[g] = ldv[g][0] * vv[g][0] + ldv[g][1] * vv[g][1] + ldv[g][2] * vv[g][2];
     sv[g] = rdlane(val[g], kSelfLane);
   }
+  NM_BSTAMP(11);
 #pragma unroll
   for (int g = 0; g < kNCOL; g++) {
     const real tol = hull_tie_tol<real>();
@@ -1036,21 +1052,26 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
         if (hop == kMaxHop || !wany(nbv & (val[g] > vr(sv[g] + tol)))) { full = true; break; }
         real bv;
         wargmax(sel(nbv, val[g], vr(real(-1e30))), nb[g], &bv, &si);
+        NM_BSTAMP(12);
         hull_ring(M, vadr + si, si, nb[g], vv[g]);
         val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
         sv[g] = rdlane(val[g], kSelfLane);
+        NM_BSTAMP(14);
         sh.nhop += 1;
       }
       if (full) {
+        NM_BSTAMP(12);
         si = support_exhaustive(M, ld, nvert, vadr);
-        sh.nfallback += 1;
+        sh.hcache[7] += 1;
         hull_ring(M, vadr + si, si, nb[g], vv[g]);
         val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
         sv[g] = rdlane(val[g], kSelfLane);
+        NM_BSTAMP(15);
       }
       if (si != cur[g]) sh.hcache[g] = si;
     }
   }
+  NM_BSTAMP(12);
   int total = 0;   // contacts found so far (not capped)
 #pragma unroll
   for (int g = 0; g < kNCOL; g++) {
@@ -1058,32 +1079,35 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     const real* p = sh.colp + 3 * g;
     const real dist = pz[g] - sv[g];
     const bool hitg = near[g] && dist < real(0);
-    vr pnt[3];
-    matvec3(pnt, R, vv[g]);
-    pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
-    const real first[3] = {rdlane(pnt[0], kSelfLane), rdlane(pnt[1], kSelfLane), rdlane(pnt[2], kSelfLane) - real(0.5) * dist};
-    // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
-    const real tol = M.tol_planemesh * M.colc[kColN * g + 3];
-    vr dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
-    vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
-    const VB ok = nbl & (nb[g] >= 0) & (val[g] > vr(pz[g])) & !(vsqrt(d2) < vr(tol));
-    const uint64_t m = ballot(ok);
-    const int nextra = vmin(popc64(m), 3);
-    const V<int> rank = lane_rank(m);
-    const VB self = lane == kSelfLane;
-    const V<int> slot = sel(self, V<int>(total), rank + (total + 1));
-    const VB wr = VB(hitg) & (self | (ok & (rank < 3))) & (slot < kMaxConBig);
-    const V<int> sl = sel(wr, slot, V<int>(0));
-    const vr cd = sel(self, vr(dist), pnt[2] + bz);
-    stsv(sh.cpos(), sl * 3, pnt[0], wr);
-    stsv(sh.cpos(), sl * 3 + 1, pnt[1], wr);
-    stsv(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr);
-    stsv(sh.cdist(), sl, cd, wr);
-    stsv(sh.cleg(), sl, g - 1, wr);
-    stsv(sh.cleg1(), sl, -1, wr);
-    stsv(sh.cnrm(), sl * 3, real(0), wr);
-    stsv(sh.cnrm(), sl * 3 + 1, real(0), wr);
-    stsv(sh.cnrm(), sl * 3 + 2, real(1), wr);
+    int nextra = 0;
+    if (uniform(hitg)) {   // most meshes do not touch the floor in a given substep: their contact emission is skipped, not masked
+      vr pnt[3];
+      matvec3(pnt, R, vv[g]);
+      pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
+      const real first[3] = {rdlane(pnt[0], kSelfLane), rdlane(pnt[1], kSelfLane), rdlane(pnt[2], kSelfLane) - real(0.5) * dist};
+      // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
+      const real tol = M.tol_planemesh * M.colc[kColN * g + 3];
+      vr dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
+      vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
+      const VB ok = nbl & (nb[g] >= 0) & (val[g] > vr(pz[g])) & !(vsqrt(d2) < vr(tol));
+      const uint64_t m = ballot(ok);
+      nextra = vmin(popc64(m), 3);
+      const V<int> rank = lane_rank(m);
+      const VB self = lane == kSelfLane;
+      const V<int> slot = sel(self, V<int>(total), rank + (total + 1));
+      const VB wr = (self | (ok & (rank < 3))) & (slot < kMaxConBig);
+      const V<int> sl = sel(wr, slot, V<int>(0));
+      const vr cd = sel(self, vr(dist), pnt[2] + bz);
+      stsv(sh.cpos(), sl * 3, pnt[0], wr);
+      stsv(sh.cpos(), sl * 3 + 1, pnt[1], wr);
+      stsv(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr);
+      stsv(sh.cdist(), sl, cd, wr);
+      stsv(sh.cleg(), sl, g - 1, wr);
+      stsv(sh.cleg1(), sl, -1, wr);
+      stsv(sh.cnrm(), sl * 3, real(0), wr);
+      stsv(sh.cnrm(), sl * 3 + 1, real(0), wr);
+      stsv(sh.cnrm(), sl * 3 + 2, real(1), wr);
+    }
     const int ng = hitg ? 1 + nextra : 0;
     const int c0 = vmin(total, kMaxConBig), c1 = vmin(total + ng, kMaxConBig);
     sh.cstart[g] = c0;
@@ -1095,10 +1119,12 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
   sh.ncon = ncon;
   sh.anypair = 0;
   wave_sync();
+  NM_BSTAMP(13);
   nm_stamp(3);
   if (pairs) stage_collide_pairs(sh, M, dropped);
   nm_stamp(4);
 }
+
 
 // =========================================================================================  stage C
 // Runs f(0), f(1), ... f(ncon-1) with compile-time indices (the A matrix lives in registers, so row numbers must be constants)
@@ -1306,8 +1332,8 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr A[kMaxRow];
 #pragma unroll
   for (int i = 0; i < kMaxRow; i++) A[i] = vr(real(0));
-#pragma unroll
-  for (int cc = 0; cc < kMaxCon; cc++) {
+  auto build_contact = [&](auto ccT) {
+    constexpr int cc = decltype(ccT)::value;
     if (cc < ncon) {
       const int Lcc = uniform(sh.cleg()[cc]);
       const VB same = onleg & (L == Lcc);
@@ -1336,7 +1362,13 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       A[4 * cc + 2] = a3[0] + M.mu * a3[2];
       A[4 * cc + 3] = a3[0] - M.mu * a3[2];
     }
-  }
+  };
+  // a flat chain of 16 guarded bodies: nesting them (one exit branch instead of one skipped test per unused contact) makes the
+  // register allocator spill 20-300 VGPRs and measured no faster
+#define NM_BUILD4(c0) build_contact(std::integral_constant<int, c0>{}); build_contact(std::integral_constant<int, c0 + 1>{}); \
+                      build_contact(std::integral_constant<int, c0 + 2>{}); build_contact(std::integral_constant<int, c0 + 3>{});
+  NM_BUILD4(0) NM_BUILD4(4) NM_BUILD4(8) NM_BUILD4(12)
+#undef NM_BUILD4
   // own diagonal entry (needed as 1/AR_ii)
   vr Ajj = u[0] * xb[0] + u[1] * xb[1] + u[2] * xb[2] + u[3] * xb[3] + u[4] * xb[4] + u[5] * xb[5] + (Jl[0] * t[0] + Jl[1] * t[1] + Jl[2] * t[2]);
   if (anypair) Ajj += Jm[0] * t1m[0] + Jm[1] * t1m[1] + Jm[2] * t1m[2];   // the two bodies of a pair are different legs
@@ -2092,7 +2124,6 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   stsv(sh.warm, lane, w_in, lane < kNV);
   stsv(sh.hcache, lane, hc_in, lane < 8);
   sh.nwarn = 0;
-  sh.nfallback = 0;
   sh.nhop = 0;
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
   V<float> af = a_in * M.action_scale;
@@ -2166,6 +2197,10 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     gstv(dbg, V<int>(161), to_real<real>(sh.nwarn), lane == 0);
     gstv(dbg, V<int>(162), to_real<real>(dropped), lane == 0);
     gstv(dbg, lane + 165, ldsv(sh.cnrm(), sel(lane < 6, lane, V<int>(0))), lane < 6);
+    gstv(dbg, lane + 150, to_real<real>(ldsv(sh.hcache, sel(lane < 7, lane, V<int>(0)))), lane < 7);
+    gstv(dbg, V<int>(158), to_real<real>(sh.hcache[7]), lane == 0);
+    gstv(dbg, V<int>(159), to_real<real>(sh.nhop), lane == 0);
+    gstv(dbg, V<int>(157), to_real<real>(sh.anypair), lane == 0);
     gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
     gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
     gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);
@@ -2182,13 +2217,8 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     if (threadIdx.x == 0) { nm_consume(atomicAdd(A.stat_cnt + 1, dropped)); nm_consume(atomicAdd(A.stat_cnt + 2, sh.nwarn)); }
 #endif
   }
-  if (A.stat_cnt && sh.nfallback) {
-#ifndef NM_EMUL
-    if (threadIdx.x == 0) nm_consume(atomicAdd(A.stat_cnt + 3, sh.nfallback));
-#endif
-  }
   if (A.physics_only) return;
-  nm_stamp(11);
+  NM_ESTAMP(11);
 
   // ---- E3 (env.py:212-232): frame transforms with the POST-integration quaternion, stale cvel/sensors
   int64_t eplen = (((int64_t)sh.eplen_hi << 32) | (int64_t)(uint32_t)sh.eplen_lo) + 1;
@@ -2259,7 +2289,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     if (sizeof(real) == 8) reset = reset | (vacos(-pg[2] / nrm) > real(1.0471975511965976));
     else reset = reset | (-pg[2] / nrm <= real(0.5));
   }
-  nm_stamp(12);
+  NM_ESTAMP(12);
   // ---- E6 (env.py:274, 335-371): reset BEFORE rewards/obs: qpos0, zero velocity, new command, episode stats
   vr epsum[1];
   V<int> l8c = sel(lane < kNREW, lane, V<int>(0));
@@ -2281,7 +2311,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #endif
     epsum[0] = vr(real(0));
   }
-  nm_stamp(13);
+  NM_ESTAMP(13);
   // ---- E7 (env.py:277-288, 399-497): rewards (alphabetical, termination last)
   real rt[kNREW];
 #pragma unroll
@@ -2349,7 +2379,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     for (int k = 0; k < kNREW; k++) add = wrlane(add, rt[k], k);
     gstv(A.epsum, lane + env * kNREW, epsum[0] + add, lane < kNREW);
   }
-  nm_stamp(14);
+  NM_ESTAMP(14);
   // ---- E8 (env.py:291-311): observation (66), clipped, float32
   {
     real head[12] = {blv[0] * M.obs_lin, blv[1] * M.obs_lin, blv[2] * M.obs_lin, bav[0] * M.obs_ang, bav[1] * M.obs_ang, bav[2] * M.obs_ang,
@@ -2383,7 +2413,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     put(dofvel * M.obs_dofvel, lane + 30, l18);
     put(act, lane + 48, l18);
   }
-  nm_stamp(15);
+  NM_ESTAMP(15);
   // ---- buffers the reference keeps between steps
   gstv(A.dofpos, lane + env * kNU, dofpos, l18);
   gstv(A.dofvel, lane + env * kNU, dofvel, l18);

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -46,10 +47,9 @@ template <class real> __device__ __noinline__ void step_tail(const nm::Args<real
   if (lane == 0) {
     A.counters[0] += __hip_atomic_load(A.stat_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A.counters[1] += __hip_atomic_load(A.stat_cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    A.counters[2] += __hip_atomic_load(A.stat_cnt + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     A.stat_cnt[0] = 0; A.stat_cnt[1] = 0; A.stat_cnt[2] = 0; A.stat_cnt[3] = 0;
     *A.nto = 0;
-    *A.wave_done = 0;
+    A.wave_done[nm::kTicketTop] = 0;
   }
 }
 
@@ -60,6 +60,7 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   __shared__ nm::Args<real> As;    // ... and of the launch arguments: ~30 pointers would otherwise pin 60 SGPRs for the whole kernel
   const int wave = blockIdx.x;
   if (wave * G >= A.N) return;
+  const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   As = A;
   {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(Mp);
@@ -68,13 +69,29 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
     __syncthreads();
   }
   nm::wave_step<real, G>(sh, Ms, As, wave);
+  if (As.dbg && threadIdx.x == 0) {   // debug buffer only: start / end clock of this wave as exact 24-bit pieces (scripts/wavetimes.py)
+    const unsigned long long t_end = __builtin_amdgcn_s_memtime();
+    real* d = As.dbg + (size_t)(wave * G) * nm::kDbgN + 250;
+    d[0] = (real)(unsigned)(t_start & 0xFFFFFF); d[1] = (real)(unsigned)((t_start >> 24) & 0xFFFFFF);
+    d[2] = (real)(unsigned)(t_end & 0xFFFFFF); d[3] = (real)(unsigned)((t_end >> 24) & 0xFFFFFF);
+  }
   if (As.physics_only) return;
   // The wave that finishes last closes the step (what used to be a second launch). What it needs from the others went through
   // device-scope atomics whose results each wave has already consumed (nm_consume), so the ticket needs no fence.
+  // Two-level ticket: waves draw from their group's counter, the last wave of a group from the top counter - at most 64 + 32
+  // same-address atomics in a row instead of gridDim.x.
+  const int nw = (int)gridDim.x, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
+  const int gsize = min(nm::kTicketGroup, nw - grp * nm::kTicketGroup);
   int ticket = 0;
-  if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done, 1);
+  if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done + (grp + 1) * nm::kTicketStride, 1);
   ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != (int)gridDim.x - 1) return;
+  if (ticket != gsize - 1) return;
+  if (threadIdx.x == 0) {
+    As.wave_done[(grp + 1) * nm::kTicketStride] = 0;     // every member has drawn: re-arm for the next launch
+    ticket = atomicAdd(As.wave_done + nm::kTicketTop, 1);
+  }
+  ticket = __builtin_amdgcn_readfirstlane(ticket);
+  if (ticket != ngrp - 1) return;
   step_tail<real>(As, Ms.ep_len_s);
 }
 
@@ -177,7 +194,25 @@ template <class real> struct Env : nm_env {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_ev;
   size_t prof_used = 0;
 
+  // All device memory of an env comes out of ONE slab (a multiple of 2 MiB): the driver maps large allocations with 2 MiB
+  // page-table fragments, so the shared hull tables and the per-env rows stay within a handful of TLB entries instead of one
+  // 4 KiB-granular mapping per small hipMalloc.
+  char* slab = nullptr;
+  size_t slab_size = 0, slab_used = 0;
+  int slab_init(size_t bytes) {
+    slab_size = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    HIPCHK(hipMalloc((void**)&slab, slab_size));
+    HIPCHK(hipMemset(slab, 0, slab_size));
+    allocs.push_back(slab);
+    return 0;
+  }
   template <class X> int dalloc(X** p, size_t n) {
+    const size_t bytes = (n * sizeof(X) + 255) & ~(size_t)255;
+    if (slab && slab_used + bytes <= slab_size) {
+      *p = (X*)(slab + slab_used);
+      slab_used += bytes;
+      return 0;
+    }
     HIPCHK(hipMalloc((void**)p, n * sizeof(X)));
     HIPCHK(hipMemset(*p, 0, n * sizeof(X)));
     allocs.push_back(*p);
@@ -197,13 +232,16 @@ template <class real> struct Env : nm_env {
     memset(&M, 0, sizeof M);
     memset(&A, 0, sizeof A);
     T.fill_scalars(M, cfg);
+    if (const char* e = getenv("NM_MEASURE_PGS_ITERS")) M.pgs_iters = atoi(e);        // measurement only (results change): cost per sweep
+    if (const char* e = getenv("NM_MEASURE_NOSLIP_ITERS")) M.noslip_iters = atoi(e);
+    if (slab_init((T.hullv.size() + T.hullnv.size()) * sizeof(real) + (size_t)n * 300 * sizeof(real) + (size_t)n * 64 + (1u << 20))) return 1;
     if (upload(&M.hullv, T.hullv) || upload(&M.hullnv, T.hullnv)) return 1;
     A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
     size_t n_ = (size_t)N;
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
         dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * nm::kNREW) || dalloc(&A.feetair, n_ * nm::kNLEG) || dalloc(&A.feetflags, n_) ||
         dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, nm::kNREW) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
-        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, 1) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_))
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, ((n_ + nm::kTicketGroup - 1) / nm::kTicketGroup + 2) * nm::kTicketStride) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_))
       return 1;
     if (dalloc(&M_dev, 1)) return 1;
     HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));
@@ -354,7 +392,11 @@ template <class real> struct Env : nm_env {
     HIPCHK(hipDeviceSynchronize());
     long long c[3];
     HIPCHK(hipMemcpy(c, counters_dev, sizeof c, hipMemcpyDeviceToHost));
-    out[0] = c[0]; out[1] = c[1]; out[2] = c[2];
+    std::vector<int> hc((size_t)N * 8);
+    HIPCHK(hipMemcpy(hc.data(), A.hullcache, hc.size() * sizeof(int), hipMemcpyDeviceToHost));
+    long long fb = 0;
+    for (int i = 0; i < N; i++) fb += hc[(size_t)i * 8 + 7];    // per-env running counts (wrap after 2^31 fallbacks of one env)
+    out[0] = c[0]; out[1] = c[1]; out[2] = fb;
     return 0;
   }
   int set_noise(const double* vec) override {

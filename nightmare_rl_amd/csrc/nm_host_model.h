@@ -111,7 +111,9 @@ template <class real> struct Tables {
             row[4 * j + 3] = (real)n;
           }
           for (int k = 0; k < 3; k++) row[4 * NM_HULL_MAXNBR + k] = (real)nm_hull_vert[vadr + i][k];
-          row[4 * NM_HULL_MAXNBR + 3] = (real)i;
+          int deg = 0;
+          for (int j = 0; j < NM_HULL_MAXNBR; j++) deg += nm_hull_nbr[vadr + i][j] >= 0;
+          row[4 * NM_HULL_MAXNBR + 3] = (real)(i + 1024 * deg);   // own local id (< 1024) and degree, exact in fp32
         }
       }
     }

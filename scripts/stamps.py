@@ -17,8 +17,15 @@ env._L.nm_read_stamps(out, 0)
 names = ["load", "check+normalise", "A smooth", "B floor collision", "B tibia pairs", "C rows+project (A matrix)", "C warm start+PGS",
          "C noslip", "C J'f+sensors", "D integrate", "epilogue: buffers + lane-0 stores", "epilogue: state stores", "epilogue: E3-E5 frames/termination", "epilogue: E6 reset",
          "epilogue: E7 rewards", "epilogue: E8 observation"]
+if os.environ.get("NM_STAMPS_B"):   # measurement build with -DNM_STAMPS_B
+    names[3] = "B (rest)"
+    names[11:14] = ["B ring gather + support values", "B hill climbs / fallbacks", "B contact emission"]
+    names[10] = "epilogue (all)"
+    names[14], names[15] = "B   of which: hop ring gathers", "B   of which: exhaustive scan + ring"
 waves = (N + 1) // 2
 tot = sum(out[:16])
 for k, n in enumerate(names):
     print(f"{n:28s} {out[k] / K / waves:10.0f} ticks/wave/step  {100.0 * out[k] / tot:5.1f} %")
+c = env.counters()
+print("fallbacks per wave-step:", c["hull_search_fallbacks"] / (500 * waves))
 print(f"{'total':28s} {tot / K / waves:10.0f} ticks/wave/step (s_memtime ticks)")

@@ -36,6 +36,7 @@ def lib():
         L.emu_record.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_configure.argtypes = [C.c_void_p] * 3
         L.emu_feet.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        L.emu_hull_cache.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_eplen.argtypes = [C.c_void_p]
         L.emu_eplen.restype = C.POINTER(C.c_int64)
         _lib = L
@@ -89,6 +90,12 @@ class EmulEnv:
         air = np.ascontiguousarray(air, np.float64)
         fl = ((np.asarray(last, np.int32) << np.arange(6)).sum(1) | (np.asarray(filt, np.int32) << (6 + np.arange(6))).sum(1)).astype(np.int32)
         self.L.emu_feet(self.h, 1, _p(air), _p(fl))
+
+    def hull_cache(self, value=None):
+        """[N,8] ints: warm-start vertex of the 7 colliding meshes + the env's running exhaustive-scan count; set when `value` given."""
+        hc = np.zeros((self.N, 8), np.int32) if value is None else np.ascontiguousarray(value, np.int32).reshape(self.N, 8)
+        self.L.emu_hull_cache(self.h, int(value is not None), _p(hc))
+        return hc
 
     def set_noise(self, vec=None, u=None):
         f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)

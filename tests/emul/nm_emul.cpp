@@ -21,6 +21,7 @@ struct EmuBase {
   virtual void record(int env, double* out50) = 0;
   virtual void configure(const double* scales, const double* modes6) = 0;
   virtual void feet(int set, double* air, int* flags) = 0;
+  virtual void hull_cache(int set, int* hc) = 0;
 };
 
 template <class real> struct Emu : EmuBase {
@@ -53,6 +54,9 @@ template <class real> struct Emu : EmuBase {
     cfg.tibia_contact_mode = (int)m[0]; cfg.tibia_max_contact_force = m[1]; cfg.body_contact_mode = (int)m[2]; cfg.body_max_contact_force = m[3];
     cfg.base_height_target = m[4]; cfg.max_contact_force = m[5];
     T.fill_scalars(M, cfg);
+  }
+  void hull_cache(int set, int* hc) override {
+    for (size_t i = 0; i < hcache.size(); i++) { if (set) hcache[i] = hc[i]; else hc[i] = hcache[i]; }
   }
   void feet(int set, double* air, int* flags) override {
     for (size_t i = 0; i < feetair.size(); i++) { if (set) feetair[i] = (real)air[i]; else air[i] = (double)feetair[i]; }
@@ -127,6 +131,7 @@ void emu_set_noise(void* h, const double* vec, const double* u) { ((EmuBase*)h)-
 void emu_record(void* h, int env, double* out50) { ((EmuBase*)h)->record(env, out50); }
 void emu_configure(void* h, const double* scales, const double* modes6) { ((EmuBase*)h)->configure(scales, modes6); }
 void emu_feet(void* h, int set, double* air, int* flags) { ((EmuBase*)h)->feet(set, air, flags); }
+void emu_hull_cache(void* h, int set, int* hc) { ((EmuBase*)h)->hull_cache(set, hc); }
 int emu_nrew() { return nm::kNREW; }
 int emu_dbg_n() { return nm::kDbgN; }
 }

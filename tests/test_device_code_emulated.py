@@ -96,6 +96,34 @@ def test_free_run_tracks_oracle(emul, oracle_mod):
         np.testing.assert_allclose(rew, orew, atol=5e-4)
 
 
+def test_any_vertex_is_a_valid_warm_start_of_the_hull_search(emul, oracle_mod):
+    """The support search starts from last step's vertex; force it to start from the widest fan centres of every hull (34
+    neighbours, never a support vertex in practice): results must still equal the oracle's, step after step."""
+    from nightmare_rl_amd.model.compile_model import load_tables
+    T = load_tables()
+    deg = (T["hull_nbr"] >= 0).sum(1)
+    wide = []
+    for g in range(7):
+        va, nv = int(T["col_vadr"][g]), int(T["col_nvert"][g])
+        wide.append(int(np.argmax(deg[va:va + nv])))
+        assert deg[va + wide[-1]] > 15
+    N, rng = 6, np.random.default_rng(3)
+    e = emul.EmulEnv(N, double=True, seed=2)
+    o = oracle_mod.OracleEnv(N, seed=2)
+    for t in range(25):                       # fall from the reset height onto the floor
+        a = rng.uniform(-1, 1, (N, 18)).astype(np.float32)
+        if t in (0, 12, 20):
+            e.hull_cache(np.tile(np.array(wide + [0], np.int32), (N, 1)))
+        obs, rew, done, _ = e.step(a)
+        oobs, orew, odone, _ = o.step(a)
+        np.testing.assert_array_equal(done, odone)
+        np.testing.assert_allclose(obs, oobs, atol=2e-7)
+        np.testing.assert_allclose(e.get("qvel"), o.get_state()[1], atol=1e-9)
+    assert max(o.data(i).ncon for i in range(N)) > 0
+    hc = e.hull_cache()
+    assert not any((hc[:, g] == wide[g]).all() for g in range(1, 7))       # the search moved away from the forced start
+
+
 def test_counter_rng_matches_oracle(emul, oracle_mod):
     """Command resampling draws: device code and oracle share the (seed, global env id, counter) generator."""
     N = 5
