@@ -125,22 +125,59 @@ int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count);
  * bit2 whole constraint stage, bit3 smooth-dynamics stage. 0 = normal. */
 int nm_set_ablation(nm_env* env, int32_t mask);
 
-/* ActorCritic.act mean path (rsl_rl v1.0.2 ActorCritic: Linear->ELU x n_hidden -> Linear), batched over envs
- * on the MFMA units. weights: device f32, layer l is [out_l, in_l] row-major followed by bias [out_l]
- * (torch.nn.Linear layout); dims = {66, h1, ..., 18}, n_layers = len(dims)-1. */
-int nm_policy_forward(const float* obs_dev, int32_t num_envs, const float* const* weights_dev, const float* const* bias_dev,
-                      const int32_t* dims, int32_t n_layers, float* actions_dev, void* stream);
-
-/* The same in two halves, for weights that stay fixed over many calls (a rollout, play.py): nm_policy_pack repacks the
- * weights for the fused kernel (networks of <= 4 layers, <= 256 units; one packed network per process),
- * nm_policy_forward_packed runs the last packed network - one launch per policy step. */
-int nm_policy_pack(const float* const* weights_dev, const float* const* bias_dev, const int32_t* dims, int32_t n_layers, void* stream);
-int nm_policy_forward_packed(const float* obs_dev, int32_t num_envs, float* actions_dev, void* stream);
+/* ---- ActorCritic MLP forward on the matrix cores (rsl_rl v1.0.2 ActorCritic: Linear -> ELU x n_hidden -> Linear; reference call
+ * sites play.py:122 `nn.act(obs)`, train.py:40), batched over envs, exact-f32 MFMA, all layers in one launch.
+ * One handle = one network: it owns a packed copy of the parameters, so nothing is shared between networks, streams or devices.
+ * dims = {n_in, h1, ..., n_out}, n_layers = len(dims) - 1. Networks of <= 4 layers and <= 256 units run fused; others per layer. */
+typedef struct nm_policy nm_policy;
+int nm_policy_create(const int32_t* dims, int32_t n_layers, int32_t device, nm_policy** out);
+int nm_policy_destroy(nm_policy* h);
+/* Copy + repack the parameters (device f32, torch.nn.Linear layout: weights[l] is [out_l, in_l] row-major, bias[l] is [out_l]).
+ * Stream-ordered; call again after every optimiser step / load_state_dict - the handle never reads the caller's tensors later. */
+int nm_policy_load(nm_policy* h, const float* const* weights_dev, const float* const* bias_dev, void* stream);
+/* out_dev[N, n_out] = MLP(obs_dev[N, n_in]) with the parameters of the last nm_policy_load. One launch on the fused path. */
+int nm_policy_forward(nm_policy* h, const float* obs_dev, int32_t num_envs, float* out_dev, void* stream);
 
 /* GAE(lambda) returns of one rollout (rsl_rl v1.0.2 RolloutStorage.compute_returns; caller reference train.py:54).
  * rewards/values/returns [T,N] f32, dones [T,N] u8, last_values [N] f32, all device memory. */
 int nm_gae(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev,
            int32_t T, int32_t N, float gamma, float lam, float* returns_dev, void* stream);
+
+/* Rollout collection of the on-policy loop (rsl_rl v1.0.2 PPO.act / PPO.process_env_step; caller reference train.py:54), one launch each.
+ * nm_ppo_sample: net_out_dev [N, A+1] = action means | critic value (nm_policy_forward on the merged actor+critic network), std_dev [A];
+ *   draws a = mean + std * N(0,1) from the counter generator keyed by (seed, *iter_dev, step, env, j) and writes step `step` of the rollout
+ *   storage: actions/mu/sigma [N,A], log-probability and value [N], and (if obs_store_dev != NULL) a copy of obs_dev [N, n_obs].
+ * nm_ppo_record: rewards_store = rew + gamma * value * time_out (time_outs_dev may be NULL), dones_store (u8), running episode return /
+ *   length per env, and fin3_dev += (sum of returns, sum of lengths, count) over the episodes that ended in this step. */
+int nm_ppo_sample(const float* net_out_dev, const float* std_dev, const float* obs_dev, int32_t N, int32_t A, int32_t n_obs, uint64_t seed,
+                  const int64_t* iter_dev, int32_t step, float* actions_dev, float* logp_dev, float* values_dev, float* mu_dev, float* sigma_dev,
+                  float* obs_store_dev, void* stream);
+int nm_ppo_record(const float* rew_dev, const int64_t* done_dev, const float* time_outs_dev, const float* values_dev, float gamma, int32_t N,
+                  float* rewards_store_dev, unsigned char* dones_store_dev, float* cur_ret_dev, float* cur_len_dev, float* fin3_dev, void* stream);
+
+/* ---- PPO mini-batch update (rsl_rl v1.0.2 `algorithms/ppo.py` PPO.update: clipped surrogate + clipped value loss + entropy bonus,
+ * adaptive-KL learning rate, gradient-norm clipping, Adam; caller reference train.py:54; hyper-parameters envs/nightmare_v3_config.py:111-128)
+ * as four launches per mini-batch with no host synchronisation. actor_dims / critic_dims = {n_obs, h1, ..., n_out} (same depth, same
+ * observation, critic output 1, ELU). The parameters live in ONE caller-owned flat device vector in the order
+ * actor W0 b0 W1 b1 ..., critic W0 b0 ..., std[A] (W row-major [out, in] as torch.nn.Linear); Adam's moments in two more such vectors. */
+typedef struct nm_ppo nm_ppo;
+int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_dims, int32_t n_layers, int32_t device, nm_ppo** out);
+int nm_ppo_destroy(nm_ppo* h);
+int32_t nm_ppo_num_params(const nm_ppo* h);
+/* (re)read the flat parameters (after load_state_dict or a step taken elsewhere) and set the learning rate / Adam step count */
+int nm_ppo_sync_params(nm_ppo* h, const float* flat_dev, float lr, int64_t step, void* stream);
+/* one mini-batch: rows of obs [B,n_obs], actions / old_mu / old_sigma [B,A], old_logp / adv / ret / target_values [B] (device f32).
+ * phase 0 = everything; 1 = gradient only (fetch it with nm_ppo_copy_grad, e.g. for an all-reduce); 2 = the step from the current gradient
+ * (kl_override >= 0 replaces the local KL mean in the learning-rate rule, < 0 keeps it). */
+int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
+                     const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* target_values,
+                     int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
+                     int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
+/* gradient of the last mini-batch, flat order [num_params]: direction 0 copies it to grad_dev, 1 replaces it by grad_dev */
+int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream);
+/* HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, grad norm;
+ * reset_sums != 0 clears the two loss sums and the count afterwards. Synchronises the stream. */
+int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream);
 
 /* ---- scripted gait / IK engine (reference nikengine/engine.py; caller custom_play.py:49-76), batched over envs ----
  * One handle = num_envs independent EngineNode objects (engine.py:660-677), all in IdleState. */

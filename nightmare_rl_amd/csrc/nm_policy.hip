@@ -1,102 +1,183 @@
-// nm_policy.hip - ActorCritic actor forward (rsl_rl v1.0.2 ActorCritic.act mean path; reference call sites
-// play.py:122, train.py:40) as a batched GEMM chain on the matrix cores: exact-f32 MFMA (v_mfma_f32_32x32x2_f32),
-// bias + ELU fused into the accumulator epilogue.
+// nm_policy.hip - ActorCritic MLP forward (rsl_rl v1.0.2 ActorCritic: Linear -> ELU ... -> Linear; reference call sites
+// play.py:122, train.py:40) as a batched GEMM chain on the matrix cores: exact-f32 MFMA (v_mfma_f32_16x16x4_f32), bias + ELU fused
+// into the accumulator epilogue, all layers in ONE launch.
 //
-// Fused path (all dims <= 256, <= 4 layers): one workgroup of 8 waves owns 16 envs; activations ping-pong between two
-// padded LDS tiles, weights stream from L2 as one 16-byte load per lane per 4 k-steps; a wave computes 32x32 output
-// tiles. One launch per policy step. Layers that do not fit use the per-layer kernel.
+// Shape of the problem: M = num_envs rows (4096), K, N <= 256: 0.7 GFLOP for 66->256->256->18 - a small GEMM chain whose floor is
+// the matrix pipe (16 rows per CU on 256 CUs: 1360 MFMAs per CU = 10.9k cycles). Design:
+//   * one workgroup of 8 waves (two per SIMD) owns 16 rows; activations ping-pong between two LDS tiles;
+//   * weights are packed ONCE per parameter update (nm_policy_load) into the exact per-lane order of the MFMA B operand, so a
+//     lane fetches 4 k-steps with one 16-byte load (coalesced 1 KiB per wave instruction, L2-resident: 0.35 MB per network);
+//     K is padded to 16 (not 64): 66 -> 80;
+//   * activations sit in LDS as [row][k mod 4][k div 4], so a lane's 4 k-steps are one ds_read_b128;
+//   * a wave runs two accumulator chains (two 16-column tiles) to hide the 40-cycle dependent latency behind the 32-cycle issue;
+//   * narrow layers (the 18-wide head: 2 tiles for 8 waves) split K across the waves and reduce through LDS.
+// State lives in a handle (nm_policy): packed weights, layer table, scratch - one per network, no process-wide statics.
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/nightmare_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int kTileRows = 16, kMaxDim = 256, kLd = kMaxDim + 1, kMaxLayers = 4;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// Wt[k][o] = W[o][k] for k < K, 0 for K <= k < Kpad: torch.nn.Linear layout -> what the MFMA B operand wants
-// (coalesced over output units), K padded to the 64-deep chunk of the main loop so that loop needs no predicates.
-__global__ void k_transpose_pad(const float* __restrict__ W, float* __restrict__ Wt, int O, int K, int Kpad) {
-  int i = blockIdx.x * blockDim.x + threadIdx.x;   // i = k * O + o over the padded matrix (coalesced writes)
-  if (i < O * Kpad) { int k = i / O, o = i - k * O; Wt[i] = k < K ? W[(size_t)o * K + k] : 0.0f; }
-}
+extern "C" int nm_policy_set_error(const char* m);
+
+constexpr int kTileRows = 16, kMaxDim = 256, kMaxLayers = 4;
+constexpr int kMlpThreads = 512, kMlpWaves = kMlpThreads / 64;
+constexpr int kMaxSteps = kMaxDim / 4;            // k-steps of 4 per layer (one MFMA 16x16x4 each)
+constexpr int kQStride = kMaxSteps + 4;           // floats between the four (k mod 4) planes of a row: 16 B aligned, and the 16 columns a
+                                                  // wave's epilogue stores per instruction land in 16 different banks (64 would put 4 in one)
+constexpr int kActLd = 4 * kQStride + 4;          // floats per activation row in LDS (16 B aligned; 8 consecutive rows cover all banks)
 
 struct MlpArgs {
-  const float* w[kMaxLayers];   // transposed + padded
+  const f32x4* w[kMaxLayers];   // packed: [tile][group of 4 k-steps][lane] -> 4 consecutive k-steps of that lane
   const float* b[kMaxLayers];
   int dims[kMaxLayers + 1];
   int n_layers, N;
 };
 
-// One workgroup (8 waves, two per SIMD) owns 16 envs; activations ping-pong between two padded LDS tiles. A wave computes 16x16 output
-// tiles with v_mfma_f32_16x16x4_f32 (exact f32), TWO tiles at a time so the two accumulator chains hide the 40-cycle
-// dependent latency behind the 32-cycle issue interval. Lane (r = l&15, q = l>>4) feeds A[i=r][k=k0+q], B[k=k0+q][j=r].
-constexpr int kMlpThreads = 512;   // 8 waves: one pass over the 16 column tiles of a 256-wide layer, two waves per SIMD
+// W [O,K] row-major (torch.nn.Linear) -> packed B operand: lane (r = l & 15, q = l >> 4) of tile t needs, at k-step s,
+// W[16 t + r][4 s + q]; zero beyond K or O.
+__global__ void k_pack_weights(const float* __restrict__ W, f32x4* __restrict__ P, int O, int K, int ngrp, int ntile) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= ntile * ngrp * 64) return;
+  const int lane = i & 63, gs = (i >> 6) % ngrp, t = (i >> 6) / ngrp;
+  const int r = lane & 15, q = lane >> 4, col = 16 * t + r;
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k = 4 * (4 * gs + j) + q;
+    v[j] = (col < O && k < K) ? W[(size_t)col * K + k] : 0.0f;
+  }
+  P[i] = v;
+}
+
+__device__ __forceinline__ int act_pos(int k) { return (k & 3) * kQStride + (k >> 2); }   // position of input k inside a row
+
+// what one wave does in one layer: a pair of 16-column tiles and a range of k-groups (narrow layers split K over the waves)
+struct WavePlan {
+  int ntile, ngrp, split, part, g0, g1, t0, t1;
+  bool work, two;
+  const f32x4 *w0, *w1;
+};
+__device__ __forceinline__ WavePlan plan_layer(const MlpArgs& a, int l, int wave, int lane) {
+  WavePlan p;
+  const int K = a.dims[l], O = a.dims[l + 1];
+  p.ntile = (O + 15) >> 4; p.ngrp = (K + 15) >> 4;
+  const int npair = (p.ntile + 1) >> 1;
+  // split K over 2^lg waves per tile pair when the layer is narrow (fewer pairs than waves) AND deep enough to be worth a
+  // reduction round (>= 4 k-groups per part); shifts only, no integer division
+  int lg = 0;
+  while ((npair << (lg + 1)) <= kMlpWaves && (p.ngrp >> (lg + 1)) >= 4) lg++;
+  p.split = 1 << lg;
+  const int pr = wave >> lg;
+  p.part = wave & (p.split - 1);
+  p.g0 = (p.ngrp * p.part) >> lg; p.g1 = (p.ngrp * (p.part + 1)) >> lg;
+  p.work = pr < npair;
+  p.t0 = 2 * pr; p.t1 = min(2 * pr + 1, p.ntile - 1);
+  p.two = 2 * pr + 1 < p.ntile;
+  p.w0 = a.w[l] + ((size_t)(p.work ? p.t0 : 0) * p.ngrp) * 64 + lane;
+  p.w1 = a.w[l] + ((size_t)(p.work ? p.t1 : 0) * p.ngrp) * 64 + lane;
+  return p;
+}
+
+#ifdef NM_MLP_STAMPS   // measurement build: cycle stamps of workgroup 0 (scripts/mlpstamps.py)
+__device__ unsigned long long g_mlp_stamps[16];
+#define MLP_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mlp_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int nm_mlp_read_stamps(unsigned long long* out16) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mlp_stamps), sizeof(g_mlp_stamps)) == hipSuccess ? 0 : 1;
+}
+#else
+#define MLP_STAMP(k)
+#endif
+
 __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restrict__ obs, float* __restrict__ out, MlpArgs a) {
-  __shared__ float act[2][kTileRows * kLd];
+  __shared__ __attribute__((aligned(16))) float act[2][kTileRows * kActLd];
+  __shared__ __attribute__((aligned(16))) float red[kMlpWaves][8][64];     // split-K partial accumulators of narrow layers
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * kTileRows;
-  for (int i = tid; i < 2 * kTileRows * kLd; i += kMlpThreads) (&act[0][0])[i] = 0.0f;   // padded k-columns must be finite
-  __syncthreads();
-  {  // stage the observation tile (coalesced rows)
-    const int K = a.dims[0];
-    for (int i = tid; i < kTileRows * K; i += kMlpThreads) {
-      int rr = i / K, kk = i - rr * K;
-      act[0][rr * kLd + kk] = (row0 + rr < a.N) ? obs[(size_t)(row0 + rr) * K + kk] : 0.0f;
+  MLP_STAMP(0);
+  // the first weights of layer 0 are in flight while the observation tile is staged (they do not depend on it)
+  WavePlan p = plan_layer(a, 0, wave, lane);
+  f32x4 c0 = p.w0[(size_t)p.g0 * 64], c1 = p.w1[(size_t)p.g0 * 64];
+  f32x4 n0 = c0, n1 = c1;
+  if (p.g0 + 1 < p.g1) { n0 = p.w0[(size_t)(p.g0 + 1) * 64]; n1 = p.w1[(size_t)(p.g0 + 1) * 64]; }
+  {  // stage the observation tile: wave w takes rows 2w and 2w+1 (coalesced), permuted to the [k mod 4][k div 4] layout; the
+     // k positions between K and the next multiple of 16 are zeroed (the packed weights are zero there, LDS garbage may be NaN)
+    const int K = a.dims[0], Kp = (K + 15) & ~15;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int rr = 2 * wave + h;
+      for (int kk = lane; kk < Kp; kk += 64)
+        act[0][rr * kActLd + act_pos(kk)] = (kk < K && row0 + rr < a.N) ? obs[(size_t)(row0 + rr) * K + kk] : 0.0f;
     }
   }
   __syncthreads();
+  MLP_STAMP(1);
   for (int l = 0; l < a.n_layers; l++) {
-    const int K = a.dims[l], O = a.dims[l + 1];
+    const int O = a.dims[l + 1], Op = (O + 15) & ~15;
     const bool last = l == a.n_layers - 1;
-    const float* __restrict__ Wt = a.w[l];
     const float* __restrict__ B = a.b[l];
-    const float* xrow = act[l & 1] + r * kLd;
+    const float* x = act[l & 1] + r * kActLd + q * kQStride;     // this lane's A operand: row r, inputs k = 4 s + q
     float* y = act[(l + 1) & 1];
-    const int ntile = (O + 15) / 16, nch = (K + 63) >> 6;
-    for (int t = wave * 2; t < ntile; t += 2 * (kMlpThreads / 64)) {   // this wave: tiles t and t+1
-      const int c0 = t * 16 + r, c1 = c0 + 16;
-      const bool ok0 = c0 < O, ok1 = c1 < O;
-      const float* w0 = Wt + (ok0 ? c0 : 0);
-      const float* w1 = Wt + (ok1 ? c1 : 0);
-      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
-      float cur0[16], cur1[16], nx0[16], nx1[16];
+    f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+    // biases of this wave's two column tiles: requested now, needed in the epilogue
+    const int bc0 = 16 * p.t0 + r, bc1 = 16 * p.t1 + r;
+    const float bias0 = (p.work && bc0 < O) ? B[bc0] : 0.0f, bias1 = (p.work && bc1 < O) ? B[bc1] : 0.0f;
+    if (p.work) {
+      f32x4 av = *reinterpret_cast<const f32x4*>(x + 4 * p.g0);
+      for (int gs = p.g0; gs < p.g1; gs++) {
+        f32x4 f0 = n0, f1 = n1;
+        if (gs + 2 < p.g1) { f0 = p.w0[(size_t)(gs + 2) * 64]; f1 = p.w1[(size_t)(gs + 2) * 64]; }   // weights: two groups ahead
+        const f32x4 an = *reinterpret_cast<const f32x4*>(x + 4 * min(gs + 1, p.g1 - 1));             // activations: one group ahead
 #pragma unroll
-      for (int j = 0; j < 16; j++) { cur0[j] = w0[(size_t)(4 * j + q) * O]; cur1[j] = w1[(size_t)(4 * j + q) * O]; }
-      for (int c = 0; c < nch; c++) {
-        const int kb = (c << 6) + q;
-        if (c + 1 < nch) {
-#pragma unroll
-          for (int j = 0; j < 16; j++) { nx0[j] = w0[(size_t)(kb + 64 + 4 * j) * O]; nx1[j] = w1[(size_t)(kb + 64 + 4 * j) * O]; }
+        for (int j = 0; j < 4; j++) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c0[j], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c1[j], acc1, 0, 0, 0);
         }
-        float av[16];
-#pragma unroll
-        for (int j = 0; j < 16; j++) av[j] = xrow[kb + 4 * j];
-#pragma unroll
-        for (int j = 0; j < 16; j++) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cur0[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], cur1[j], acc1, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < 16; j++) { cur0[j] = nx0[j]; cur1[j] = nx1[j]; }
+        c0 = n0; c1 = n1; n0 = f0; n1 = f1; av = an;
       }
-      // C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    }
+    MLP_STAMP(2 + 3 * l);
+    const WavePlan cur = p;
+    if (!last) {   // next layer's first weights: in flight across the epilogue and the barrier
+      p = plan_layer(a, l + 1, wave, lane);
+      c0 = p.w0[(size_t)p.g0 * 64]; c1 = p.w1[(size_t)p.g0 * 64];
+      n0 = c0; n1 = c1;
+      if (p.g0 + 1 < p.g1) { n0 = p.w0[(size_t)(p.g0 + 1) * 64]; n1 = p.w1[(size_t)(p.g0 + 1) * 64]; }
+    }
+    if (cur.split > 1) {   // reduce the k-parts: both accumulators parked at once, the first wave of a pair adds them up
+      if (cur.work && cur.part != 0) {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) { red[wave][reg][lane] = acc0[reg]; red[wave][4 + reg][lane] = acc1[reg]; }
+      }
+      __syncthreads();
+      if (cur.work && cur.part == 0) {
+        for (int pp = 1; pp < cur.split; pp++)
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) { acc0[reg] += red[wave + pp][reg][lane]; acc1[reg] += red[wave + pp][4 + reg][lane]; }
+      }
+    }
+    MLP_STAMP(3 + 3 * l);
+    // epilogue: C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    if (cur.work && cur.part == 0) {
 #pragma unroll
       for (int half = 0; half < 2; half++) {
-        const int col = half ? c1 : c0;
-        if (half ? ok1 : ok0) {
-          const float bias = B[col];
+        const int col = 16 * (half ? cur.t1 : cur.t0) + r;
+        if ((half == 0 || cur.two) && col < Op) {
+          const float bias = half ? bias1 : bias0;
 #pragma unroll
           for (int reg = 0; reg < 4; reg++) {
             const int rr = q * 4 + reg;
             float v = (half ? acc1[reg] : acc0[reg]) + bias;
             if (!last) {
-              v = v > 0.0f ? v : expm1f(v);
-              y[rr * kLd + col] = v;
-            } else if (row0 + rr < a.N) {
+              v = v > 0.0f ? v : __expf(v) - 1.0f;   // ELU; v_exp_f32 (1 ulp) - 1: absolute error < 1.2e-7, no libm call in the epilogue
+              y[rr * kActLd + act_pos(col)] = col < O ? v : 0.0f;   // columns up to the next multiple of 16 feed zero weights: keep them finite
+            } else if (col < O && row0 + rr < a.N) {
               out[(size_t)(row0 + rr) * O + col] = v;
             }
           }
@@ -104,10 +185,11 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restri
       }
     }
     __syncthreads();
+    MLP_STAMP(4 + 3 * l);
   }
 }
 
-// y[N,O] = act(x[N,K] W[O,K]^T + b[O]);  grid = (ceil(N/32), ceil(O/32)), block = 64   (fallback for wide layers)
+// y[N,O] = act(x[N,K] W[O,K]^T + b[O]);  grid = (ceil(N/32), ceil(O/32)), block = 64   (fallback for layers wider than 256)
 __global__ void __launch_bounds__(64) k_linear_mfma(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
                                                     float* __restrict__ y, int N, int K, int O, int elu) {
   const int lane = threadIdx.x, r = lane & 31, h = lane >> 5;
@@ -138,17 +220,19 @@ __global__ void __launch_bounds__(64) k_linear_mfma(const float* __restrict__ x,
   }
 }
 
-static float* g_wt = nullptr;   // transposed weights of the fused path (repacked every call: weights change between PPO updates)
-static size_t g_wt_n = 0;
-static int g_wt_dev = -1;
-static float* g_scratch[2] = {nullptr, nullptr};
-static size_t g_scratch_n = 0;
-static int g_scratch_dev = -1;
-extern "C" int nm_policy_set_error(const char* m);
-
-static MlpArgs g_packed;          // layer table of the last nm_policy_pack (device pointers into g_wt / the caller's biases)
-static bool g_packed_ok = false;
-static int g_packed_dev = -1;
+// ------------------------------------------------------------------------------------------------ handle
+struct nm_policy {
+  int device = 0, n_layers = 0;
+  std::vector<int> dims;
+  bool fused = false, loaded = false;
+  f32x4* packed = nullptr;            // fused path: packed weights of all layers
+  float* bias = nullptr;              // own copy of the biases (the handle never points into caller memory)
+  float* wcopy = nullptr;             // per-layer path: own copy of the weights, torch layout
+  std::vector<size_t> w_off, b_off, p_off;
+  float* scratch[2] = {nullptr, nullptr};
+  size_t scratch_n = 0;
+  MlpArgs args;
+};
 
 static bool mlp_fits(const int32_t* dims, int32_t n_layers) {
   bool fits = n_layers <= kMaxLayers;
@@ -156,75 +240,104 @@ static bool mlp_fits(const int32_t* dims, int32_t n_layers) {
   return fits;
 }
 
-extern "C" int nm_policy_pack(const float* const* weights, const float* const* bias, const int32_t* dims, int32_t n_layers, void* stream) {
-  if (!weights || !bias || !dims || n_layers <= 0) return nm_policy_set_error("nm_policy_pack: bad argument");
-  if (!mlp_fits(dims, n_layers)) return nm_policy_set_error("nm_policy_pack: network too large for the fused kernel (<= 4 layers of <= 256 units)");
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_pack: no HIP device");
-  g_packed_ok = false;
-  MlpArgs a;
-  a.n_layers = n_layers; a.N = 0;
-  size_t tot = 0;
-  for (int l = 0; l < n_layers; l++) tot += (size_t)((dims[l] + 63) & ~63) * dims[l + 1];
-  if (tot > g_wt_n || dev != g_wt_dev) {
-    if (g_wt) (void)hipFree(g_wt);
-    g_wt = nullptr; g_wt_n = 0;
-    if (hipMalloc((void**)&g_wt, tot * sizeof(float)) != hipSuccess) return nm_policy_set_error("nm_policy_pack: hipMalloc failed");
-    g_wt_n = tot; g_wt_dev = dev;
-  }
-  size_t off = 0;
+extern "C" int nm_policy_create(const int32_t* dims, int32_t n_layers, int32_t device, nm_policy** out) {
+  if (!out) return nm_policy_set_error("nm_policy_create: out is NULL");
+  *out = nullptr;
+  if (!dims || n_layers <= 0) return nm_policy_set_error("nm_policy_create: bad argument");
+  for (int l = 0; l <= n_layers; l++)
+    if (dims[l] <= 0) return nm_policy_set_error("nm_policy_create: layer sizes must be positive");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nm_policy_set_error("nm_policy_create: no such HIP device");
+  if (hipSetDevice(device) != hipSuccess) return nm_policy_set_error("nm_policy_create: hipSetDevice failed");
+  nm_policy* h = new nm_policy();
+  h->device = device; h->n_layers = n_layers;
+  h->dims.assign(dims, dims + n_layers + 1);
+  h->fused = mlp_fits(dims, n_layers);
+  size_t wtot = 0, btot = 0, ptot = 0;
   for (int l = 0; l < n_layers; l++) {
-    int kpad = (dims[l] + 63) & ~63, n = kpad * dims[l + 1];
-    hipLaunchKernelGGL(k_transpose_pad, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, weights[l], g_wt + off, dims[l + 1], dims[l], kpad);
-    a.w[l] = g_wt + off; a.b[l] = bias[l];
-    off += n;
+    h->w_off.push_back(wtot); h->b_off.push_back(btot); h->p_off.push_back(ptot);
+    wtot += (size_t)dims[l] * dims[l + 1];
+    btot += (size_t)dims[l + 1];
+    ptot += (size_t)((dims[l + 1] + 15) / 16) * ((dims[l] + 15) / 16) * 64;
   }
-  for (int l = 0; l <= n_layers; l++) a.dims[l] = dims[l];
-  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_pack: launch failed");
-  g_packed = a; g_packed_ok = true; g_packed_dev = dev;
+  bool ok = hipMalloc((void**)&h->bias, btot * sizeof(float)) == hipSuccess;
+  if (ok && h->fused) ok = hipMalloc((void**)&h->packed, ptot * sizeof(f32x4)) == hipSuccess;
+  if (ok && !h->fused) ok = hipMalloc((void**)&h->wcopy, wtot * sizeof(float)) == hipSuccess;
+  if (!ok) { nm_policy_destroy(h); return nm_policy_set_error("nm_policy_create: hipMalloc failed"); }
+  *out = h;
   return 0;
 }
 
-extern "C" int nm_policy_forward_packed(const float* obs, int32_t N, float* actions, void* stream) {
-  if (!obs || !actions || N <= 0) return nm_policy_set_error("nm_policy_forward_packed: bad argument");
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_forward_packed: no HIP device");
-  if (!g_packed_ok || dev != g_packed_dev) return nm_policy_set_error("nm_policy_forward_packed: no packed network on this device (call nm_policy_pack)");
-  MlpArgs a = g_packed;
-  a.N = N;
-  hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(kMlpThreads), 0, (hipStream_t)stream, obs, actions, a);
-  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward_packed: launch failed");
+extern "C" int nm_policy_destroy(nm_policy* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->packed) (void)hipFree(h->packed);
+  if (h->bias) (void)hipFree(h->bias);
+  if (h->wcopy) (void)hipFree(h->wcopy);
+  for (int i = 0; i < 2; i++) if (h->scratch[i]) (void)hipFree(h->scratch[i]);
+  delete h;
   return 0;
 }
 
-extern "C" int nm_policy_forward(const float* obs, int32_t N, const float* const* weights, const float* const* bias, const int32_t* dims,
-                                 int32_t n_layers, float* actions, void* stream) {
-  if (!obs || !weights || !bias || !dims || !actions || N <= 0 || n_layers <= 0) return nm_policy_set_error("nm_policy_forward: bad argument");
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess) return nm_policy_set_error("nm_policy_forward: no HIP device");
-  if (mlp_fits(dims, n_layers)) {
-    if (nm_policy_pack(weights, bias, dims, n_layers, stream)) return 1;
-    return nm_policy_forward_packed(obs, N, actions, stream);
-  }
-  size_t maxh = 0;
-  for (int l = 1; l < n_layers; l++) maxh = (size_t)dims[l] > maxh ? (size_t)dims[l] : maxh;
-  size_t need = (size_t)N * (maxh ? maxh : 1);
-  if (n_layers > 1 && (need > g_scratch_n || dev != g_scratch_dev)) {
-    for (int i = 0; i < 2; i++) {
-      if (g_scratch[i]) (void)hipFree(g_scratch[i]);
-      if (hipMalloc((void**)&g_scratch[i], need * sizeof(float)) != hipSuccess) return nm_policy_set_error("nm_policy_forward: hipMalloc failed");
+// copy (and, on the fused path, repack) the parameters: call after every optimiser step / load_state_dict. Stream-ordered.
+extern "C" int nm_policy_load(nm_policy* h, const float* const* weights, const float* const* bias, void* stream) {
+  if (!h || !weights || !bias) return nm_policy_set_error("nm_policy_load: bad argument");
+  if (hipSetDevice(h->device) != hipSuccess) return nm_policy_set_error("nm_policy_load: hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  for (int l = 0; l < h->n_layers; l++) {
+    const int K = h->dims[l], O = h->dims[l + 1];
+    if (!weights[l] || !bias[l]) return nm_policy_set_error("nm_policy_load: NULL parameter pointer");
+    if (hipMemcpyAsync(h->bias + h->b_off[l], bias[l], (size_t)O * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return nm_policy_set_error("nm_policy_load: bias copy failed");
+    if (h->fused) {
+      const int ntile = (O + 15) / 16, ngrp = (K + 15) / 16, n = ntile * ngrp * 64;
+      hipLaunchKernelGGL(k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, s, weights[l], h->packed + h->p_off[l], O, K, ngrp, ntile);
+      h->args.w[l] = h->packed + h->p_off[l];
+    } else if (hipMemcpyAsync(h->wcopy + h->w_off[l], weights[l], (size_t)O * K * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
+      return nm_policy_set_error("nm_policy_load: weight copy failed");
     }
-    g_scratch_n = need;
-    g_scratch_dev = dev;
+    h->args.b[l] = h->bias + h->b_off[l];
+  }
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_load: launch failed");
+  for (int l = 0; l <= h->n_layers && l <= kMaxLayers; l++) h->args.dims[l] = h->dims[l];
+  h->args.n_layers = h->n_layers;
+  h->loaded = true;
+  return 0;
+}
+
+extern "C" int nm_policy_forward(nm_policy* h, const float* obs, int32_t N, float* out, void* stream) {
+  if (!h || !obs || !out || N <= 0) return nm_policy_set_error("nm_policy_forward: bad argument");
+  if (!h->loaded) return nm_policy_set_error("nm_policy_forward: no parameters loaded (nm_policy_load)");
+  if (hipSetDevice(h->device) != hipSuccess) return nm_policy_set_error("nm_policy_forward: hipSetDevice failed");
+  hipStream_t s = (hipStream_t)stream;
+  if (h->fused) {
+    MlpArgs a = h->args;
+    a.N = N;
+    hipLaunchKernelGGL(k_mlp_fused, dim3((N + kTileRows - 1) / kTileRows), dim3(kMlpThreads), 0, s, obs, out, a);
+    if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward: launch failed");
+    return 0;
+  }
+  size_t maxh = 1;
+  for (int l = 1; l < h->n_layers; l++) maxh = (size_t)h->dims[l] > maxh ? (size_t)h->dims[l] : maxh;
+  const size_t need = (size_t)N * maxh;
+  if (h->n_layers > 1 && need > h->scratch_n) {
+    for (int i = 0; i < 2; i++) {
+      if (h->scratch[i]) (void)hipFree(h->scratch[i]);
+      h->scratch[i] = nullptr;
+      if (hipMalloc((void**)&h->scratch[i], need * sizeof(float)) != hipSuccess) return nm_policy_set_error("nm_policy_forward: hipMalloc failed");
+    }
+    h->scratch_n = need;
   }
   const float* in = obs;
-  for (int l = 0; l < n_layers; l++) {
-    const bool last = l == n_layers - 1;
-    float* out = last ? actions : g_scratch[l & 1];
-    dim3 grid((N + 31) / 32, (dims[l + 1] + 31) / 32);
-    hipLaunchKernelGGL(k_linear_mfma, grid, dim3(64), 0, (hipStream_t)stream, in, weights[l], bias[l], out, N, dims[l], dims[l + 1], last ? 0 : 1);
+  for (int l = 0; l < h->n_layers; l++) {
+    const bool last = l == h->n_layers - 1;
+    float* o = last ? out : h->scratch[l & 1];
+    dim3 grid((N + 31) / 32, (h->dims[l + 1] + 31) / 32);
+    hipLaunchKernelGGL(k_linear_mfma, grid, dim3(64), 0, s, in, h->wcopy + h->w_off[l], h->bias + h->b_off[l], o, N, h->dims[l], h->dims[l + 1],
+                       last ? 0 : 1);
     if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_forward: launch failed");
-    in = out;
+    in = o;
   }
   return 0;
 }

@@ -1,0 +1,513 @@
+// nm_ppo.hip - PPO mini-batch update of rsl_rl v1.0.2 (`algorithms/ppo.py` PPO.update; caller reference train.py:54) on hand-written
+// kernels: forward of actor and critic, the clipped-surrogate / clipped-value / entropy losses, the whole backward pass, gradient-norm
+// clipping, the KL-adaptive learning rate and Adam - four launches per mini-batch, no host synchronisation, instead of ~60 framework
+// launches (elementwise chains on [81920 x 54] activations + library GEMMs with K = 82 k).
+//
+// The two MLPs (reference envs/nightmare_v3_config.py:107-109: 66 -> 54 -> 42 -> 30 -> 18 and -> 1, ELU) run as ONE merged network:
+// actor and critic side by side, block-diagonal hidden layers, the bias of a layer stored as one more weight column fed by a constant
+// 1 - so forward, dX and dW are three plain GEMM shapes per layer, all on exact-f32 MFMA (v_mfma_f32_16x16x4_f32):
+//     forward   a_l  = ELU(a_{l-1} Wm_l')              A = activations [16 rows x K],  B = packed Wm_l   (k-major per lane)
+//     dX        d_{l-1} = (d_l Wm_l) * ELU'(a_{l-1})   A = deltas      [16 rows x O],  B = packed Wm_l'  (o-major per lane)
+//     dW        G_l += d_l' a_{l-1}                    A = deltas^T, B = activations, reduction over the 16 rows of the tile
+// k_ppo_fwdbwd: a workgroup of 8 waves walks its share of the mini-batch in tiles of 16 rows; activations and deltas live in LDS
+//   ([row][k mod 4][k div 4]: the A operand of 4 k-steps is one ds_read_b128); the dW accumulators stay in registers for the whole
+//   walk (<= 16 tiles of 16x16 per wave) and are written once per workgroup as a partial gradient. The loss head (one wave) turns the
+//   network output into d(loss)/d(mean), d(loss)/d(value), and accumulates d(loss)/d(std), the KL to the behaviour policy and the
+//   loss values.
+// k_ppo_reduce : partial gradients -> gradient of every real parameter (merged-matrix position looked up in a table) + squared norm.
+// k_ppo_scalars: KL mean -> learning rate (rsl_rl's adaptive schedule), clip coefficient, loss statistics, std gradient.
+// k_ppo_adam   : Adam step on the flat parameter vector, then the two packed copies of the merged weights for the next mini-batch.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <vector>
+
+#include "../../include/nightmare_hip.h"
+
+extern "C" int nm_policy_set_error(const char* m);
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+constexpr int kL = 4;                      // layers of the merged network (<=)
+constexpr int kW = 128;                    // widest padded layer
+constexpr int kQS = kW / 4 + 4;            // stride between the four (k mod 4) planes of a row
+constexpr int kLD = 4 * kQS + 4;           // floats per LDS row
+constexpr int kRows = 16;
+constexpr int kThreads = 512, kWaves = 8;
+constexpr int kSlots = 16;                 // dW tiles a wave can own
+constexpr int kMaxA = 32;                  // actions (<=)
+constexpr int kNS = 40;                    // per-workgroup scalars: dstd[32], kl, surrogate, value loss, count, pad
+
+struct PpoNet {
+  int n_layers;
+  int Kr[kL], Or[kL];          // real inputs (without the bias column) / outputs of the merged layers
+  int Kp[kL], Op[kL];          // padded to 16 (Kp includes the bias column)
+  int goff[kL];                // offset of layer l's [Op x Kp] block in a merged gradient vector
+  int gtotal;                  // floats per merged gradient (without the scalars)
+  int A;                       // actions; the critic value is output column A
+  const f32x4* pf[kL];         // forward packing   [O tile][k group][lane]
+  const f32x4* pb[kL];         // backward packing  [K tile][o group][lane]
+  int slot[kWaves][kSlots];    // dW tiles of wave w: layer | o tile << 4 | k tile << 8, -1 = none (tile g of the network goes to wave g % 8)
+};
+struct PpoBatch {
+  const float *obs, *actions, *old_mu, *old_sigma, *old_logp, *adv, *ret, *tval, *std;
+  int B, n_obs;
+  float clip, vcoef, inv_B;
+  int clip_value;
+};
+
+__device__ __forceinline__ int pos(int c) { return (c & 3) * kQS + (c >> 2); }
+
+__global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt, float* __restrict__ partial) {
+  __shared__ __attribute__((aligned(16))) float act[kL][kRows * kLD];      // inputs of layer l (a_0 = observation), with the 1-column
+  __shared__ __attribute__((aligned(16))) float outb[kRows * kLD];         // network output: means | value
+  __shared__ __attribute__((aligned(16))) float dl[2][kRows * kLD];        // deltas, ping-pong
+  __shared__ float hs[kRows][8];                                           // per-row scalars of the loss head
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 15, q = lane >> 4;
+  const int ntiles = (bt.B + kRows - 1) / kRows;
+  // ---- this wave's dW tiles (table built on the host)
+  int s_l[kSlots], s_to[kSlots], s_tk[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; s++) {
+    const int code = net.slot[wave][s];
+    s_l[s] = code < 0 ? -1 : (code & 15); s_to[s] = (code >> 4) & 15; s_tk[s] = (code >> 8) & 15;
+  }
+  f32x4 gw[kSlots];
+#pragma unroll
+  for (int s = 0; s < kSlots; s++) gw[s] = f32x4{0, 0, 0, 0};
+  float a_dstd[kMaxA / 4], a_kl = 0.0f, a_surr = 0.0f, a_vl = 0.0f;       // head accumulators (wave 0; lane-local partials)
+#pragma unroll
+  for (int it = 0; it < kMaxA / 4; it++) a_dstd[it] = 0.0f;
+
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int row0 = tile * kRows;
+    // ---- stage the observation tile (+ the constant 1 that carries the bias); wave w takes rows 2w, 2w+1
+    {
+      const int K = net.Kr[0], Kp = net.Kp[0];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int rr = 2 * wave + h, row = row0 + rr;
+        for (int kk = lane; kk < Kp; kk += 64) {
+          float v = 0.0f;
+          if (row < bt.B) v = kk < K ? bt.obs[(size_t)row * bt.n_obs + kk] : (kk == K ? 1.0f : 0.0f);
+          act[0][rr * kLD + pos(kk)] = v;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- forward
+    for (int l = 0; l < net.n_layers; l++) {
+      const bool last = l == net.n_layers - 1;
+      const int ngrp = net.Kp[l] >> 4, ntile = net.Op[l] >> 4, Or = net.Or[l];
+      const float* x = act[l] + r * kLD + q * kQS;
+      float* y = last ? outb : act[l + 1];
+      for (int t = wave; t < ntile; t += kWaves) {
+        const f32x4* __restrict__ w = net.pf[l] + ((size_t)t * ngrp) * 64 + lane;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int g = 0; g < ngrp; g++) {
+          const f32x4 wv = w[(size_t)g * 64];
+          const f32x4 av = *reinterpret_cast<const f32x4*>(x + 4 * g);
+#pragma unroll
+          for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc, 0, 0, 0);
+        }
+        const int col = 16 * t + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int rr = q * 4 + reg;
+          float v = acc[reg];
+          if (!last) v = col < Or ? (v > 0.0f ? v : __expf(v) - 1.0f) : (col == Or ? 1.0f : 0.0f);   // ELU | bias carrier | padding
+          y[rr * kLD + pos(col)] = v;
+        }
+      }
+      __syncthreads();
+    }
+    // ---- loss head (wave 0): lane (row r, q) handles actions q, q+4, ...; d(loss)/d(output) -> dl[0]
+    if (wave == 0) {
+      const int row = row0 + r, A = net.A;
+      const bool live = row < bt.B;
+      float lp = 0.0f, kl = 0.0f;
+      for (int j = q; j < A; j += 4) {
+        if (live) {
+          const float mu = outb[r * kLD + pos(j)], sd = bt.std[j];
+          const float a = bt.actions[(size_t)row * A + j], omu = bt.old_mu[(size_t)row * A + j], osd = bt.old_sigma[(size_t)row * A + j];
+          const float z = (a - mu) / sd;
+          lp += -0.5f * z * z - __logf(sd) - 0.9189385332046727f;
+          kl += __logf(sd / osd + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) / (2.0f * sd * sd) - 0.5f;
+        }
+      }
+      lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+      kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
+      float dlogp = 0.0f;      // d(surrogate)/d(logp) * (1/B)
+      if (live) {
+        const float adv = bt.adv[row], ratio = __expf(lp - bt.old_logp[row]);
+        const float s1 = -adv * ratio, rc = fminf(fmaxf(ratio, 1.0f - bt.clip), 1.0f + bt.clip), s2 = -adv * rc;
+        const bool inside = ratio > 1.0f - bt.clip && ratio < 1.0f + bt.clip;
+        // torch.max(s1, s2).backward(): the larger branch gets the gradient, a tie (ratio inside the clip range) splits it between
+        // two identical branches; the clipped branch has zero slope outside the range
+        const float g1 = s1 > s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f), g2 = 1.0f - g1;
+        dlogp = (g1 * (-adv * ratio) + g2 * (inside ? -adv * ratio : 0.0f)) * bt.inv_B;
+        if (q == 0) {
+          a_surr += fmaxf(s1, s2);
+          a_kl += kl;
+          const float v = outb[r * kLD + pos(A)], R = bt.ret[row], tv = bt.tval[row];
+          float dv, vl;
+          if (bt.clip_value) {
+            const float dvt = v - tv, vc = tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
+            const float l1 = (v - R) * (v - R), l2 = (vc - R) * (vc - R);
+            const bool in2 = dvt > -bt.clip && dvt < bt.clip;
+            const float h1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), h2 = 1.0f - h1;
+            vl = fmaxf(l1, l2);
+            dv = h1 * 2.0f * (v - R) + h2 * (in2 ? 2.0f * (vc - R) : 0.0f);
+          } else {
+            vl = (R - v) * (R - v);
+            dv = 2.0f * (v - R);
+          }
+          a_vl += vl;
+          hs[r][0] = dv * bt.vcoef * bt.inv_B;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      // deltas of the output layer: columns j < A: dlogp * (a - mu)/sd^2, column A: value, the rest 0; and this tile's part of
+      // d(loss)/d(std_j) = sum over rows of dlogp * ((a-mu)^2/sd^3 - 1/sd): lane (r, q) owns j = q + 4 it, rows summed over the 16-lane row
+#pragma unroll
+      for (int it = 0; it < kMaxA / 4 + 1; it++) {
+        const int c = q + 4 * it;
+        if (c < net.Op[net.n_layers - 1]) {
+          float d = 0.0f, ds = 0.0f;
+          if (live && c < A) {
+            const float mu = outb[r * kLD + pos(c)], sd = bt.std[c], a = bt.actions[(size_t)row * A + c];
+            d = dlogp * (a - mu) / (sd * sd);
+            ds = dlogp * ((a - mu) * (a - mu) / (sd * sd * sd) - 1.0f / sd);
+          } else if (live && c == A) {
+            d = hs[r][0];
+          }
+          dl[0][r * kLD + pos(c)] = d;
+          ds += __shfl_xor(ds, 1); ds += __shfl_xor(ds, 2); ds += __shfl_xor(ds, 4); ds += __shfl_xor(ds, 8);
+          if (it < kMaxA / 4) a_dstd[it] += ds;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- backward
+    for (int l = net.n_layers - 1; l >= 0; l--) {
+      const float* D = dl[(net.n_layers - 1 - l) & 1];
+      float* Dn = dl[(net.n_layers - l) & 1];
+      // dW_l += D' a_{l-1}: this wave's tiles of layer l
+#pragma unroll
+      for (int s = 0; s < kSlots; s++) {
+        if (s_l[s] == l) {
+          const int co = 16 * s_to[s] + r, ck = 16 * s_tk[s] + r;
+          const float* dp = D + q * kLD + pos(co);
+          const float* ap = act[l] + q * kLD + pos(ck);
+#pragma unroll
+          for (int st = 0; st < 4; st++)
+            gw[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(dp[4 * st * kLD], ap[4 * st * kLD], gw[s], 0, 0, 0);
+        }
+      }
+      // d_{l-1} = (D Wm_l) * ELU'(a_{l-1})
+      if (l > 0) {
+        const int ngrp = net.Op[l] >> 4, ntile = net.Kp[l] >> 4, Kr = net.Kr[l];
+        const float* x = D + r * kLD + q * kQS;
+        for (int t = wave; t < ntile; t += kWaves) {
+          const f32x4* __restrict__ w = net.pb[l] + ((size_t)t * ngrp) * 64 + lane;
+          f32x4 acc = {0, 0, 0, 0};
+          for (int g = 0; g < ngrp; g++) {
+            const f32x4 wv = w[(size_t)g * 64];
+            const f32x4 av = *reinterpret_cast<const f32x4*>(x + 4 * g);
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], wv[j], acc, 0, 0, 0);
+          }
+          const int col = 16 * t + r;
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) {
+            const int rr = q * 4 + reg;
+            const float a = act[l][rr * kLD + pos(col)];
+            Dn[rr * kLD + pos(col)] = col < Kr ? acc[reg] * (a > 0.0f ? 1.0f : a + 1.0f) : 0.0f;   // ELU'(z) from ELU(z); no gradient into the 1-column
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- this workgroup's partial gradient
+  float* P = partial + (size_t)blockIdx.x * (net.gtotal + kNS);
+#pragma unroll
+  for (int s = 0; s < kSlots; s++) {
+    if (s_l[s] >= 0) {
+      const int l = s_l[s], Kp = net.Kp[l];
+      const int k = 16 * s_tk[s] + r;
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int o = 16 * s_to[s] + q * 4 + reg;
+        P[net.goff[l] + o * Kp + k] = gw[s][reg];
+      }
+    }
+  }
+  if (wave == 0) {
+    a_kl += __shfl_xor(a_kl, 1); a_kl += __shfl_xor(a_kl, 2); a_kl += __shfl_xor(a_kl, 4); a_kl += __shfl_xor(a_kl, 8);
+    a_surr += __shfl_xor(a_surr, 1); a_surr += __shfl_xor(a_surr, 2); a_surr += __shfl_xor(a_surr, 4); a_surr += __shfl_xor(a_surr, 8);
+    a_vl += __shfl_xor(a_vl, 1); a_vl += __shfl_xor(a_vl, 2); a_vl += __shfl_xor(a_vl, 4); a_vl += __shfl_xor(a_vl, 8);
+    if (r == 0) {
+#pragma unroll
+      for (int it = 0; it < kMaxA / 4; it++) P[net.gtotal + q + 4 * it] = a_dstd[it];
+    }
+    if (lane == 0) { P[net.gtotal + 32] = a_kl; P[net.gtotal + 33] = a_surr; P[net.gtotal + 34] = a_vl; }
+  }
+}
+
+// merged [Op x Kp] matrices (bias in column Kr) -> the two MFMA packings
+__global__ void k_ppo_pack(const float* __restrict__ Wm, f32x4* __restrict__ pf, f32x4* __restrict__ pb, int Op, int Kp) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nf = (Op / 16) * (Kp / 16) * 64;
+  if (i >= 2 * nf) return;
+  const int which = i / nf, ii = i - which * nf;
+  const int lane = ii & 63, r = lane & 15, q = lane >> 4;
+  f32x4 v;
+  if (which == 0) {       // forward: [O tile t][k group g][lane]: Wm[16 t + r][4 (4 g + j) + q]
+    const int ngrp = Kp / 16, g = (ii >> 6) % ngrp, t = (ii >> 6) / ngrp;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = Wm[(size_t)(16 * t + r) * Kp + 4 * (4 * g + j) + q];
+    pf[ii] = v;
+  } else {                // backward: [K tile t][o group g][lane]: Wm[4 (4 g + j) + q][16 t + r]
+    const int ngrp = Op / 16, g = (ii >> 6) % ngrp, t = (ii >> 6) / ngrp;
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = Wm[(size_t)(4 * (4 * g + j) + q) * Kp + 16 * t + r];
+    pb[ii] = v;
+  }
+}
+// flat real parameters -> merged matrices (zero elsewhere: the off-diagonal blocks and the padding never change)
+__global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restrict__ map, int n, float* __restrict__ Wm_all) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && map[i] >= 0) Wm_all[map[i]] = flat[i];
+}
+// gradient of every real parameter: sum of the workgroups' partial gradients at its merged position (std: from the scalar tail,
+// plus the entropy bonus -c_e * d(sum_j log std_j)/d(std_j))
+__global__ void k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
+                             const float* __restrict__ flat, float ent_coef, float* __restrict__ grad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int m = map[i];
+  const int idx = m >= 0 ? m : gtotal + (-m - 1);
+  float g = 0.0f;
+  for (int w = 0; w < nwg; w++) g += partial[(size_t)w * stride + idx];
+  if (m < 0) g -= ent_coef / flat[i];
+  grad[i] = g;
+}
+// state: [0] lr [1] step [2] last kl [3] sum of value losses [4] sum of surrogate losses [5] mini-batches [6] clip coefficient [7] grad norm
+__global__ void k_ppo_scalars(const float* __restrict__ partial, int nwg, int stride, int gtotal, const float* __restrict__ grad, int n, float inv_B,
+                              float desired_kl, int adaptive, float max_norm, float kl_override, float* __restrict__ state) {
+  __shared__ float red[4][32];
+  const int tid = threadIdx.x;
+  float kl = 0, su = 0, vl = 0, n2 = 0;
+  for (int w = tid; w < nwg; w += blockDim.x) {
+    const float* P = partial + (size_t)w * stride + gtotal;
+    kl += P[32]; su += P[33]; vl += P[34];
+  }
+  for (int i = tid; i < n; i += blockDim.x) n2 += grad[i] * grad[i];
+  for (int o = 32; o > 0; o >>= 1) { kl += __shfl_xor(kl, o); su += __shfl_xor(su, o); vl += __shfl_xor(vl, o); n2 += __shfl_xor(n2, o); }
+  if ((tid & 63) == 0) { red[0][tid >> 6] = kl; red[1][tid >> 6] = su; red[2][tid >> 6] = vl; red[3][tid >> 6] = n2; }
+  __syncthreads();
+  if (tid == 0) {
+    kl = su = vl = n2 = 0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) { kl += red[0][w]; su += red[1][w]; vl += red[2][w]; n2 += red[3][w]; }
+    float klm = kl * inv_B;
+    if (kl_override >= 0.0f) klm = kl_override;       // multi-GPU: the caller all-reduced the KL and passes the global mean
+    float lr = state[0];
+    if (adaptive) {                                    // rsl_rl v1.0.2 PPO.update: schedule == 'adaptive'
+      if (klm > desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+      else if (klm < desired_kl / 2.0f && klm > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+    }
+    state[0] = lr;
+    state[1] += 1.0f;
+    state[2] = klm;
+    state[3] += vl * inv_B;
+    state[4] += su * inv_B;
+    state[5] += 1.0f;
+    const float norm = sqrtf(n2);
+    state[6] = fminf(1.0f, max_norm / (norm + 1e-6f));   // torch.nn.utils.clip_grad_norm_
+    state[7] = norm;
+  }
+}
+__global__ void k_ppo_adam(float* __restrict__ flat, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ grad, int n,
+                           const float* __restrict__ state, float b1, float b2, float eps, const int* __restrict__ map, float* __restrict__ Wm_all) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float lr = state[0], t = state[1], g = grad[i] * state[6];
+  const float mi = b1 * m[i] + (1.0f - b1) * g, vi = b2 * v[i] + (1.0f - b2) * g * g;
+  m[i] = mi; v[i] = vi;
+  const float bc1 = 1.0f - powf(b1, t), bc2 = 1.0f - powf(b2, t);
+  const float p = flat[i] - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + eps);      // torch.optim.Adam (no amsgrad, no weight decay)
+  flat[i] = p;
+  if (map[i] >= 0) Wm_all[map[i]] = p;
+}
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------ handle + C ABI
+struct nm_ppo {
+  int device = 0, n_layers = 0, A = 0, nparam = 0, nwg = 0, wm_total = 0;
+  PpoNet net;
+  std::vector<int> map_host;
+  int* map = nullptr;
+  float* Wm = nullptr;         // merged matrices, all layers
+  f32x4 *pf = nullptr, *pb = nullptr;
+  float *partial = nullptr, *grad = nullptr, *state = nullptr;
+  std::vector<size_t> pf_off, pb_off;
+};
+
+#define PPO_CHK(x) do { if ((x) != hipSuccess) return nm_policy_set_error("nm_ppo: " #x " failed"); } while (0)
+
+extern "C" int nm_ppo_destroy(nm_ppo* h) {
+  if (!h) return 0;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  for (void* p : {(void*)h->map, (void*)h->Wm, (void*)h->pf, (void*)h->pb, (void*)h->partial, (void*)h->grad, (void*)h->state})
+    if (p) (void)hipFree(p);
+  delete h;
+  return 0;
+}
+
+// actor_dims / critic_dims: {n_obs, h1, ..., n_out} with the same number of layers and the same input; critic output 1.
+// Flat parameter order: actor W0 b0 W1 b1 ..., critic W0 b0 ..., std[A] (W row-major [out, in] as torch.nn.Linear).
+extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_dims, int32_t n_layers, int32_t device, nm_ppo** out) {
+  if (!out) return nm_policy_set_error("nm_ppo_create: out is NULL");
+  *out = nullptr;
+  if (!actor_dims || !critic_dims || n_layers < 1 || n_layers > kL) return nm_policy_set_error("nm_ppo_create: 1..4 layers");
+  if (actor_dims[0] != critic_dims[0] || critic_dims[n_layers] != 1 || actor_dims[n_layers] > kMaxA || actor_dims[n_layers] < 1)
+    return nm_policy_set_error("nm_ppo_create: actor and critic must share the observation, critic output 1, at most 32 actions");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev) return nm_policy_set_error("nm_ppo_create: no such HIP device");
+  PPO_CHK(hipSetDevice(device));
+  nm_ppo* h = new nm_ppo();
+  h->device = device; h->n_layers = n_layers; h->A = actor_dims[n_layers];
+  PpoNet& n = h->net;
+  n.n_layers = n_layers; n.A = h->A;
+  int goff = 0;
+  for (int l = 0; l < n_layers; l++) {
+    n.Kr[l] = l == 0 ? actor_dims[0] : actor_dims[l] + critic_dims[l];
+    n.Or[l] = actor_dims[l + 1] + critic_dims[l + 1];
+    n.Kp[l] = (n.Kr[l] + 1 + 15) & ~15;
+    n.Op[l] = (n.Or[l] + 15) & ~15;
+    if (l + 1 < n_layers) n.Op[l] = (n.Or[l] + 1 + 15) & ~15;      // room for the 1-column of the next layer's input
+    if (n.Kp[l] > kW || n.Op[l] > kW) { delete h; return nm_policy_set_error("nm_ppo_create: merged layers wider than 128 are not supported"); }
+    n.goff[l] = goff;
+    goff += n.Op[l] * n.Kp[l];
+  }
+  for (int l = 0; l + 1 < n_layers; l++)
+    if (n.Op[l] != n.Kp[l + 1]) n.Op[l] = n.Kp[l + 1] = std::max(n.Op[l], n.Kp[l + 1]);
+  goff = 0;
+  for (int l = 0; l < n_layers; l++) { n.goff[l] = goff; goff += n.Op[l] * n.Kp[l]; }
+  n.gtotal = goff; h->wm_total = goff;
+  // dW tiles -> waves
+  for (int w = 0; w < kWaves; w++) for (int s = 0; s < kSlots; s++) n.slot[w][s] = -1;
+  {
+    int g = 0, cnt[kWaves] = {0};
+    for (int l = 0; l < n_layers; l++)
+      for (int to = 0; to < n.Op[l] / 16; to++)
+        for (int tk = 0; tk < n.Kp[l] / 16; tk++, g++) {
+          const int w = g % kWaves;
+          if (cnt[w] >= kSlots) { delete h; return nm_policy_set_error("nm_ppo_create: network too large (dW tiles per wave)"); }
+          n.slot[w][cnt[w]++] = l | (to << 4) | (tk << 8);
+        }
+  }
+  // flat parameter -> merged position
+  std::vector<int>& map = h->map_host;
+  for (int net_i = 0; net_i < 2; net_i++) {
+    const int32_t* d = net_i ? critic_dims : actor_dims;
+    for (int l = 0; l < n_layers; l++) {
+      const int o0 = net_i ? actor_dims[l + 1] : 0, k0 = (net_i && l > 0) ? actor_dims[l] : 0;
+      for (int o = 0; o < d[l + 1]; o++)
+        for (int k = 0; k < d[l]; k++) map.push_back(n.goff[l] + (o0 + o) * n.Kp[l] + k0 + k);
+      for (int o = 0; o < d[l + 1]; o++) map.push_back(n.goff[l] + (o0 + o) * n.Kp[l] + n.Kr[l]);
+    }
+  }
+  for (int j = 0; j < h->A; j++) map.push_back(-(j + 1));
+  h->nparam = (int)map.size();
+  hipDeviceProp_t prop;
+  PPO_CHK(hipGetDeviceProperties(&prop, device));
+  h->nwg = prop.multiProcessorCount;
+  size_t pft = 0, pbt = 0;
+  for (int l = 0; l < n_layers; l++) {
+    h->pf_off.push_back(pft); h->pb_off.push_back(pbt);
+    pft += (size_t)(n.Op[l] / 16) * (n.Kp[l] / 16) * 64;
+    pbt += (size_t)(n.Kp[l] / 16) * (n.Op[l] / 16) * 64;
+  }
+  bool ok = hipMalloc((void**)&h->map, map.size() * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->Wm, (size_t)h->wm_total * sizeof(float)) == hipSuccess &&
+            hipMalloc((void**)&h->pf, pft * sizeof(f32x4)) == hipSuccess && hipMalloc((void**)&h->pb, pbt * sizeof(f32x4)) == hipSuccess &&
+            hipMalloc((void**)&h->partial, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)) == hipSuccess &&
+            hipMalloc((void**)&h->grad, map.size() * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->state, 8 * sizeof(float)) == hipSuccess;
+  if (!ok) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: hipMalloc failed"); }
+  PPO_CHK(hipMemcpy(h->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+  PPO_CHK(hipMemset(h->Wm, 0, (size_t)h->wm_total * sizeof(float)));
+  PPO_CHK(hipMemset(h->state, 0, 8 * sizeof(float)));
+  PPO_CHK(hipMemset(h->partial, 0, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)));
+  for (int l = 0; l < n_layers; l++) { n.pf[l] = h->pf + h->pf_off[l]; n.pb[l] = h->pb + h->pb_off[l]; }
+  *out = h;
+  return 0;
+}
+extern "C" int32_t nm_ppo_num_params(const nm_ppo* h) { return h ? h->nparam : 0; }
+
+static int ppo_pack(nm_ppo* h, hipStream_t s) {
+  for (int l = 0; l < h->n_layers; l++) {
+    const int Op = h->net.Op[l], Kp = h->net.Kp[l], nthr = 2 * (Op / 16) * (Kp / 16) * 64;
+    hipLaunchKernelGGL(k_ppo_pack, dim3((nthr + 255) / 256), dim3(256), 0, s, h->Wm + h->net.goff[l], h->pf + h->pf_off[l], h->pb + h->pb_off[l], Op, Kp);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : nm_policy_set_error("nm_ppo: pack launch failed");
+}
+// (re)load the parameters from the flat vector (after load_state_dict, or a step taken elsewhere) and set learning rate / step count
+extern "C" int nm_ppo_sync_params(nm_ppo* h, const float* flat_dev, float lr, int64_t step, void* stream) {
+  if (!h || !flat_dev) return nm_policy_set_error("nm_ppo_sync_params: bad argument");
+  PPO_CHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_ppo_scatter, dim3((h->nparam + 255) / 256), dim3(256), 0, s, flat_dev, h->map, h->nparam, h->Wm);
+  const float st[8] = {lr, (float)step, 0, 0, 0, 0, 1.0f, 0};
+  PPO_CHK(hipMemcpyAsync(h->state, st, sizeof st, hipMemcpyHostToDevice, s));
+  PPO_CHK(hipStreamSynchronize(s));      // st lives on this stack frame
+  return ppo_pack(h, s);
+}
+// one mini-batch of PPO.update: forward, losses, backward, (optional: stop after the gradient for a multi-GPU all-reduce), clip, lr, Adam
+extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
+                                const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* tval,
+                                int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
+                                int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream) {
+  if (!h || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || !obs || !actions || !old_mu || !old_sigma || !old_logp || !adv || !ret || !tval || B <= 0)
+    return nm_policy_set_error("nm_ppo_minibatch: bad argument");
+  if (n_obs != h->net.Kr[0]) return nm_policy_set_error("nm_ppo_minibatch: observation width does not match the network");
+  PPO_CHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256;
+  if (phase == 0 || phase == 1) {     // 1: gradient only
+    PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value};
+    const int ntiles = (B + kRows - 1) / kRows, grid = ntiles < h->nwg ? ntiles : h->nwg;
+    if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
+    hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
+    hipLaunchKernelGGL(k_ppo_reduce, dim3(nb), dim3(256), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, h->grad);
+  }
+  if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced nm_ppo_grad()
+    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nwg, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,
+                       adaptive, max_grad_norm, kl_override, h->state);
+    hipLaunchKernelGGL(k_ppo_adam, dim3(nb), dim3(256), 0, s, flat_dev, exp_avg_dev, exp_avg_sq_dev, h->grad, h->nparam, h->state, beta1, beta2, eps, h->map, h->Wm);
+    if (ppo_pack(h, s)) return 1;
+  }
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_minibatch: launch failed");
+  return 0;
+}
+// gradient of the last mini-batch, flat order: direction 0 copies it into grad_dev, 1 replaces it by grad_dev (after an all-reduce)
+extern "C" int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream) {
+  if (!h || !grad_dev) return nm_policy_set_error("nm_ppo_copy_grad: bad argument");
+  PPO_CHK(hipSetDevice(h->device));
+  PPO_CHK(hipMemcpyAsync(direction ? h->grad : grad_dev, direction ? grad_dev : h->grad, (size_t)h->nparam * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return 0;
+}
+// HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, gradient norm.
+// reset_sums != 0 clears the loss sums and the mini-batch count afterwards. Synchronises the stream.
+extern "C" int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream) {
+  if (!h || !out8_host) return nm_policy_set_error("nm_ppo_get_state: bad argument");
+  PPO_CHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  PPO_CHK(hipMemcpyAsync(out8_host, h->state, 8 * sizeof(float), hipMemcpyDeviceToHost, s));
+  PPO_CHK(hipStreamSynchronize(s));
+  if (reset_sums) PPO_CHK(hipMemsetAsync(h->state + 3, 0, 3 * sizeof(float), s));
+  return 0;
+}

@@ -30,3 +30,78 @@ extern "C" int nm_gae(const float* rewards, const float* values, const unsigned 
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_gae: launch failed");
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------ rollout collection
+// PPO.act of rsl_rl v1.0.2 (`algorithms/ppo.py`: actor mean, Normal(mean, std).sample(), log_prob, critic value, transition record)
+// after the fused actor+critic forward (nm_policy_forward on the merged network: out[N, A+1] = action means | value):
+// one pass per env row that draws the action, evaluates its log-probability and files everything the update needs directly into
+// step s of the rollout storage - instead of ~25 elementwise launches per step.
+__device__ __forceinline__ float u24(uint64_t seed, uint64_t a, uint64_t b) {   // counter-based uniform in (0,1], 24 bits
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xD1B54A32D192ED03ull * b;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return ((float)(uint32_t)(x >> 40) + 1.0f) * (1.0f / 16777216.0f);
+}
+__global__ void k_ppo_sample(const float* __restrict__ net_out, const float* __restrict__ std, const float* __restrict__ obs, int N, int A, int n_obs,
+                             uint64_t seed, const int64_t* __restrict__ iter_dev, int step, float* __restrict__ actions, float* __restrict__ logp,
+                             float* __restrict__ values, float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ obs_store) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const uint64_t ctr = (uint64_t)iter_dev[0] * 4096ull + (uint64_t)step;
+  const float* o = net_out + (size_t)e * (A + 1);
+  float lp = 0.0f;
+  for (int j = 0; j < A; j += 2) {   // Box-Muller: two normals per pair of uniforms
+    const float u1 = u24(seed, (uint64_t)e * 64 + j, ctr), u2 = u24(seed, (uint64_t)e * 64 + j + 1, ctr);
+    const float rad = sqrtf(-2.0f * __logf(u1));
+    float sn, cs;
+    __sincosf(6.283185307179586f * u2, &sn, &cs);
+    const float z[2] = {rad * cs, rad * sn};
+    for (int h = 0; h < 2 && j + h < A; h++) {
+      const float m = o[j + h], sd = std[j + h];
+      const float a = m + sd * z[h];
+      actions[(size_t)e * A + j + h] = a;
+      mu[(size_t)e * A + j + h] = m;
+      sigma[(size_t)e * A + j + h] = sd;
+      lp += -0.5f * z[h] * z[h] - __logf(sd) - 0.9189385332046727f;   // Normal.log_prob: -(a-m)^2/(2 sd^2) - log sd - log sqrt(2 pi)
+    }
+  }
+  logp[e] = lp;
+  values[e] = o[A];
+  if (obs_store)
+    for (int k = 0; k < n_obs; k++) obs_store[(size_t)e * n_obs + k] = obs[(size_t)e * n_obs + k];
+}
+extern "C" int nm_ppo_sample(const float* net_out, const float* std, const float* obs, int32_t N, int32_t A, int32_t n_obs, uint64_t seed,
+                             const int64_t* iter_dev, int32_t step, float* actions, float* logp, float* values, float* mu, float* sigma, float* obs_store,
+                             void* stream) {
+  if (!net_out || !std || !iter_dev || !actions || !logp || !values || !mu || !sigma || N <= 0 || A <= 0 || A > 62) return nm_policy_set_error("nm_ppo_sample: bad argument");
+  hipLaunchKernelGGL(k_ppo_sample, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, net_out, std, obs, N, A, n_obs, seed, iter_dev, step, actions,
+                     logp, values, mu, sigma, obs_store);
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_sample: launch failed");
+  return 0;
+}
+
+// PPO.process_env_step + the runner's episode bookkeeping for one step: reward with the time-out bootstrap
+// (rewards += gamma * value * time_out), done flag, running episode return / length, and the sums over episodes that ended.
+__global__ void k_ppo_record(const float* __restrict__ rew, const int64_t* __restrict__ done, const float* __restrict__ time_outs,
+                             const float* __restrict__ values, float gamma, int N, float* __restrict__ rewards_store, unsigned char* __restrict__ dones_store,
+                             float* __restrict__ cur_ret, float* __restrict__ cur_len, float* __restrict__ fin3) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= N) return;
+  const float r = rew[e];
+  const bool d = done[e] > 0;
+  rewards_store[e] = r + (time_outs ? gamma * values[e] * time_outs[e] : 0.0f);
+  dones_store[e] = d ? 1 : 0;
+  const float cr = cur_ret[e] + r, cl = cur_len[e] + 1.0f;
+  if (d) { atomicAdd(fin3, cr); atomicAdd(fin3 + 1, cl); atomicAdd(fin3 + 2, 1.0f); }
+  cur_ret[e] = d ? 0.0f : cr;
+  cur_len[e] = d ? 0.0f : cl;
+}
+extern "C" int nm_ppo_record(const float* rew, const int64_t* done, const float* time_outs, const float* values, float gamma, int32_t N,
+                             float* rewards_store, unsigned char* dones_store, float* cur_ret, float* cur_len, float* fin3, void* stream) {
+  if (!rew || !done || !values || !rewards_store || !dones_store || !cur_ret || !cur_len || !fin3 || N <= 0) return nm_policy_set_error("nm_ppo_record: bad argument");
+  hipLaunchKernelGGL(k_ppo_record, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, done, time_outs, values, gamma, N, rewards_store,
+                     dones_store, cur_ret, cur_len, fin3);
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_record: launch failed");
+  return 0;
+}

@@ -1,5 +1,10 @@
-"""Actor MLP forward on the MFMA units (nm_policy_forward): the inference half of rsl_rl's ActorCritic
-(Linear -> ELU ... -> Linear), torch.nn.Linear weight layout so state_dicts load unchanged."""
+"""MLP forward on the MFMA units (nm_policy_*): the inference half of rsl_rl's ActorCritic (Linear -> ELU ... -> Linear),
+torch.nn.Linear weight layout so state_dicts load unchanged.
+
+Each network owns ONE library handle with a packed copy of its parameters. The copy is refreshed by `repack()`: explicitly (after
+an optimiser step, `load_state_dict`, or any write through `.data`) or, in `forward`, whenever the parameters' generation changed -
+detected by a cheap fingerprint (data pointers + tensor versions) plus `mark_dirty()` for writes the versions do not see. A HIP graph
+that captures `forward` replays the kernel only; after changing weights call `repack()` before the next replay."""
 import ctypes as C
 
 import torch
@@ -7,13 +12,67 @@ import torch
 from . import _lib
 
 
-class ActorMLP(torch.nn.Module):
-    _packed = None   # (id of the network whose weights sit in the library's packed buffer, its version key)
+class PackedMLP:
+    """Handle of one packed network on one device (no torch module semantics): load(weights, biases) then forward(obs)."""
 
+    def __init__(self, dims, device):
+        self.dims = [int(d) for d in dims]
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.NightmareHipError("the MLP kernels need a HIP device (no CPU path)")
+        self._L = _lib.load()
+        h = C.c_void_p()
+        arr = (C.c_int32 * len(self.dims))(*self.dims)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._L.nm_policy_create(arr, len(self.dims) - 1, idx, C.byref(h)))
+        self._h = h
+        self._out = None
+
+    def load(self, weights, biases):
+        k = len(self.dims) - 1
+        assert len(weights) == len(biases) == k
+        ws = [w.detach().to(device=self.device, dtype=torch.float32).contiguous() for w in weights]
+        bs = [b.detach().to(device=self.device, dtype=torch.float32).contiguous() for b in biases]
+        for l in range(k):
+            assert tuple(ws[l].shape) == (self.dims[l + 1], self.dims[l]) and tuple(bs[l].shape) == (self.dims[l + 1],)
+        wp = (C.c_void_p * k)(*[w.data_ptr() for w in ws])
+        bp = (C.c_void_p * k)(*[b.data_ptr() for b in bs])
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_policy_load(self._h, wp, bp, stream))
+        self._keep = (ws, bs)     # alive until the stream-ordered copy has run
+
+    def forward(self, obs, out=None):
+        if obs.dtype != torch.float32 or not obs.is_contiguous():
+            obs = obs.contiguous().float()
+        n = obs.shape[0]
+        if out is None:
+            if self._out is None or self._out.shape[0] != n:
+                self._out = torch.empty(n, self.dims[-1], device=self.device, dtype=torch.float32)   # stable address: graph capture
+            out = self._out
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_policy_forward(self._h, obs.data_ptr(), n, out.data_ptr(), stream))
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nm_policy_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class ActorMLP(torch.nn.Module):
     def __init__(self, dims=(66, 256, 256, 18)):
         super().__init__()
         self.dims = list(dims)
         self.layers = torch.nn.ModuleList(torch.nn.Linear(dims[i], dims[i + 1]) for i in range(len(dims) - 1))
+        self._packed = None
+        self._generation = None
+        self._dirty = True
 
     def torch_forward(self, x):
         for i, l in enumerate(self.layers):
@@ -22,37 +81,29 @@ class ActorMLP(torch.nn.Module):
                 x = torch.nn.functional.elu(x)
         return x
 
-    def _bind(self, n, device):
-        """(Re)build the cached C argument arrays: weight pointers, dims, and a persistent output buffer (stable
-        addresses, so a policy+env step can be captured in a HIP graph)."""
-        ptrs = tuple(p.data_ptr() for l in self.layers for p in (l.weight, l.bias))
-        key = (n, str(device), ptrs)
-        if getattr(self, "_key", None) != key:
-            k = len(self.layers)
-            self._w = (C.c_void_p * k)(*[l.weight.data_ptr() for l in self.layers])
-            self._b = (C.c_void_p * k)(*[l.bias.data_ptr() for l in self.layers])
-            self._dims = (C.c_int32 * (k + 1))(*self.dims)
-            self._out = torch.empty(n, self.dims[-1], device=device, dtype=torch.float32)
-            self._key = key
+    def _fingerprint(self):
+        return tuple((p.data_ptr(), p._version) for l in self.layers for p in (l.weight, l.bias))
+
+    def mark_dirty(self):
+        """Tell the module its parameters changed in a way tensor versions do not record (writes through `.data`, `dist.broadcast`)."""
+        self._dirty = True
+
+    def repack(self):
+        dev = self.layers[0].weight.device
+        if self._packed is None or self._packed.device != dev:
+            self._packed = PackedMLP(self.dims, dev)
+        self._packed.load([l.weight for l in self.layers], [l.bias for l in self.layers])
+        self._generation = self._fingerprint()
+        self._dirty = False
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self._dirty = True
 
     @torch.no_grad()
     def forward(self, obs):
-        L = _lib.load()
         if not obs.is_cuda:
             raise _lib.NightmareHipError("ActorMLP.forward needs a HIP tensor (no CPU path); use torch_forward on the host")
-        if obs.dtype != torch.float32 or not obs.is_contiguous():
-            obs = obs.contiguous().float()
-        self._bind(obs.shape[0], obs.device)
-        stream = C.c_void_p(torch.cuda.current_stream(obs.device).cuda_stream)
-        if max(self.dims) > 256 or len(self.layers) > 4:     # per-layer kernels
-            _lib.check(L.nm_policy_forward(obs.data_ptr(), obs.shape[0], self._w, self._b, self._dims, len(self.layers),
-                                           self._out.data_ptr(), stream))
-            return self._out
-        # weights are repacked for the fused kernel only when they changed (in-place updates bump tensor versions) or when
-        # another network was packed in between: a rollout pays one launch per policy step
-        ver = (self._key, tuple(p._version for l in self.layers for p in (l.weight, l.bias)))
-        if ActorMLP._packed != (id(self), ver):
-            _lib.check(L.nm_policy_pack(self._w, self._b, self._dims, len(self.layers), stream))
-            ActorMLP._packed = (id(self), ver)
-        _lib.check(L.nm_policy_forward_packed(obs.data_ptr(), obs.shape[0], self._out.data_ptr(), stream))
-        return self._out
+        if self._dirty or self._packed is None or self._generation != self._fingerprint() or self._packed.device != obs.device:
+            self.repack()
+        return self._packed.forward(obs)

@@ -1,0 +1,186 @@
+"""Rollout collection on hand-written kernels: what rsl_rl v1.0.2's `PPO.act` + `PPO.process_env_step` do per step (actor mean,
+critic value, Normal sample, log-probability, transition record, time-out bootstrap, episode bookkeeping; caller reference
+train.py:54) in THREE launches - the fused actor+critic forward on the matrix cores (one merged network: the two MLPs side by side,
+block-diagonal hidden layers), `nm_ppo_sample` and `nm_ppo_record` - writing straight into the rollout storage.
+
+Used by PPO when the networks qualify (`FusedCollector.supported`); otherwise PPO keeps its torch path (host tests, other
+activations). The packed copy of the parameters is refreshed once per iteration by `refresh()`, outside any captured graph."""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..policy import PackedMLP
+
+
+class FusedCollector:
+    @staticmethod
+    def supported(ac, device):
+        if torch.device(device).type != "cuda" or getattr(ac, "activation_name", None) != "elu":
+            return False
+        a = [m for m in ac.actor if isinstance(m, nn.Linear)]
+        c = [m for m in ac.critic if isinstance(m, nn.Linear)]
+        if len(a) != len(c) or len(a) > 4 or a[0].in_features != c[0].in_features or c[-1].out_features != 1 or a[-1].out_features > 62:
+            return False
+        return all(x.out_features + y.out_features <= 256 for x, y in zip(a, c)) and a[0].in_features <= 256
+
+    def __init__(self, ac, num_envs, device, seed=0):
+        self.ac, self.device, self.N = ac, torch.device(device), int(num_envs)
+        self.a_lin = [m for m in ac.actor if isinstance(m, nn.Linear)]
+        self.c_lin = [m for m in ac.critic if isinstance(m, nn.Linear)]
+        self.A = self.a_lin[-1].out_features
+        dims = [self.a_lin[0].in_features] + [x.out_features + y.out_features for x, y in zip(self.a_lin, self.c_lin)]
+        self.net = PackedMLP(dims, self.device)
+        self.out = torch.empty(self.N, self.A + 1, device=self.device)
+        self.iter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
+        self.seed = int(seed)
+        self._L = _lib.load()
+        self.refresh(0)
+
+    @torch.no_grad()
+    def refresh(self, iteration):
+        """Merge the current actor / critic parameters into the packed network and set the iteration the action noise is keyed by.
+        Call once per learning iteration, outside graph capture."""
+        ws, bs = [], []
+        for l, (x, y) in enumerate(zip(self.a_lin, self.c_lin)):
+            ws.append(torch.cat([x.weight, y.weight], 0) if l == 0 else torch.block_diag(x.weight, y.weight))
+            bs.append(torch.cat([x.bias, y.bias], 0))
+        self.net.load(ws, bs)
+        self.std = self.ac.std.detach().contiguous()
+        self.iter_dev.fill_(int(iteration))
+
+    def act(self, obs, storage):
+        """One collection step: actions for `obs`, with the whole transition filed into step `storage.step` of the storage."""
+        s = storage.step
+        if s >= storage.num_transitions_per_env:
+            raise AssertionError("Rollout buffer overflow")
+        obs = obs if (obs.dtype == torch.float32 and obs.is_contiguous()) else obs.contiguous().float()
+        self.net.forward(obs, out=self.out)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_sample(self.out.data_ptr(), self.std.data_ptr(), obs.data_ptr(), self.N, self.A, obs.shape[1], self.seed,
+                                         self.iter_dev.data_ptr(), s, storage.actions[s].data_ptr(), storage.actions_log_prob[s].data_ptr(),
+                                         storage.values[s].data_ptr(), storage.mu[s].data_ptr(), storage.sigma[s].data_ptr(),
+                                         storage.observations[s].data_ptr(), stream))
+        return storage.actions[s]
+
+    def record(self, storage, rewards, dones, time_outs, gamma, cur_ret, cur_len, fin):
+        s = storage.step
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_record(rewards.data_ptr(), dones.data_ptr(), None if time_outs is None else time_outs.data_ptr(),
+                                         storage.values[s].data_ptr(), float(gamma), self.N, storage.rewards[s].data_ptr(),
+                                         storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(), stream))
+        storage.step += 1
+
+
+class FusedUpdate:
+    """PPO.update on the nm_ppo_* kernels. The module's parameters become views of ONE flat device vector (so state_dicts, the
+    collector and everything else keep seeing live values), Adam's moments live in two more; the torch optimizer object is kept as the
+    checkpoint container: its state entries are views of those vectors."""
+
+    @staticmethod
+    def supported(ac, device):
+        if not FusedCollector.supported(ac, device):
+            return False
+        a = [m for m in ac.actor if isinstance(m, nn.Linear)]
+        c = [m for m in ac.critic if isinstance(m, nn.Linear)]
+        return all(x.out_features + y.out_features + 1 <= 128 for x, y in zip(a, c)) and a[0].in_features + 1 <= 128 and a[-1].out_features <= 32
+
+    def __init__(self, ac, optimizer, device, lr):
+        self.ac, self.opt, self.device = ac, optimizer, torch.device(device)
+        self._L = _lib.load()
+        a = [m for m in ac.actor if isinstance(m, nn.Linear)]
+        c = [m for m in ac.critic if isinstance(m, nn.Linear)]
+        self.params = [p for m in a for p in (m.weight, m.bias)] + [p for m in c for p in (m.weight, m.bias)] + [ac.std]
+        assert len(self.params) == len(list(ac.parameters()))
+        n = sum(p.numel() for p in self.params)
+        self.flat = torch.empty(n, device=self.device)
+        self.m, self.v = torch.zeros(n, device=self.device), torch.zeros(n, device=self.device)
+        off = 0
+        self.views = []
+        with torch.no_grad():
+            for p in self.params:
+                k = p.numel()
+                self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + k].view_as(p)
+                self.views.append((off, k))
+                off += k
+        adims = (C.c_int32 * (len(a) + 1))(a[0].in_features, *[m.out_features for m in a])
+        cdims = (C.c_int32 * (len(c) + 1))(c[0].in_features, *[m.out_features for m in c])
+        h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._L.nm_ppo_create(adims, cdims, len(a), idx, C.byref(h)))
+        self._h = h
+        assert self._L.nm_ppo_num_params(h) == n
+        self.A, self.n_obs = a[-1].out_features, a[0].in_features
+        self.step_count = 0
+        self._bind_optimizer_state()
+        self.sync(lr)
+
+    def _bind_optimizer_state(self):
+        """Adam's per-parameter state as views of the flat moment vectors (what optimizer.state_dict() then saves)."""
+        for p, (off, k) in zip(self.params, self.views):
+            self.opt.state[p] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.m[off:off + k].view_as(p),
+                                 "exp_avg_sq": self.v[off:off + k].view_as(p)}
+
+    def sync(self, lr):
+        """After the parameters (views of the flat vector) or the optimizer state were written by someone else - load_state_dict,
+        a broadcast: re-read them."""
+        for p, (off, k) in zip(self.params, self.views):      # a load may have re-pointed .data or replaced the optimizer's tensors
+            if p.data.data_ptr() != self.flat[off:off + k].data_ptr():
+                with torch.no_grad():
+                    self.flat[off:off + k].copy_(p.detach().reshape(-1))
+                    p.data = self.flat[off:off + k].view_as(p)
+            st = self.opt.state.get(p)
+            if st and "exp_avg" in st and st["exp_avg"].data_ptr() != self.m[off:off + k].data_ptr():
+                self.m[off:off + k].copy_(st["exp_avg"].reshape(-1))
+                self.v[off:off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count = int(float(st["step"]))
+        self._bind_optimizer_state()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_sync_params(self._h, self.flat.data_ptr(), float(lr), int(self.step_count), stream))
+
+    def minibatch(self, obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hp, phase=0, kl_override=-1.0):
+        f = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
+        obs, actions, old_mu, old_sigma = f(obs), f(actions), f(old_mu), f(old_sigma)
+        old_logp, advantages, returns, target_values = f(old_logp), f(advantages), f(returns), f(target_values)
+        b1, b2 = self.opt.param_groups[0]["betas"]
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_minibatch(self._h, self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), obs.data_ptr(), actions.data_ptr(),
+                                            old_mu.data_ptr(), old_sigma.data_ptr(), old_logp.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
+                                            target_values.data_ptr(), obs.shape[0], obs.shape[1], hp["clip"], hp["value_coef"], hp["entropy_coef"],
+                                            int(hp["clip_value"]), hp["desired_kl"], int(hp["adaptive"]), hp["max_grad_norm"], b1, b2,
+                                            self.opt.param_groups[0]["eps"], phase, kl_override, stream))
+        self._keep = (obs, actions, old_mu, old_sigma, old_logp, advantages, returns, target_values)
+        if phase != 1:
+            self.step_count += 1
+
+    def grad(self, out=None):
+        """The last mini-batch's gradient, flat parameter order (a copy on the device)."""
+        out = torch.empty_like(self.flat) if out is None else out
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_copy_grad(self._h, out.data_ptr(), 0, stream))
+        return out
+
+    def set_grad(self, g):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_copy_grad(self._h, g.contiguous().data_ptr(), 1, stream))
+
+    def read_state(self, reset_sums=True):
+        """dict(lr, steps, kl, value_loss_sum, surrogate_loss_sum, minibatches, clip_coef, grad_norm); one stream synchronisation."""
+        out = (C.c_float * 8)()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_get_state(self._h, out, int(reset_sums), stream))
+        keys = ("lr", "steps", "kl", "value_loss_sum", "surrogate_loss_sum", "minibatches", "clip_coef", "grad_norm")
+        return dict(zip(keys, [float(x) for x in out]))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nm_ppo_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -7,6 +7,7 @@ import torch.distributed as dist
 import torch.nn as nn
 import torch.optim as optim
 
+from .fused import FusedCollector, FusedUpdate
 from .storage import RolloutStorage
 
 
@@ -30,6 +31,23 @@ class PPO:
 
     def init_storage(self, num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape):
         self.storage = RolloutStorage(num_envs, num_transitions_per_env, actor_obs_shape, critic_obs_shape, action_shape, self.device)
+        # collection on the hand-written kernels when the networks qualify and the critic sees the actor's observation
+        self.fused = self.fused_update = None
+        if (critic_obs_shape is None or critic_obs_shape[0] is None) and FusedCollector.supported(self.actor_critic, self.device):
+            # the update first: it re-homes the parameters in one flat vector, which the collector then reads
+            if FusedUpdate.supported(self.actor_critic, self.device) and _world() == 1:
+                self.fused_update = FusedUpdate(self.actor_critic, self.optimizer, self.device, self.learning_rate)
+            self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=torch.initial_seed() & 0xFFFFFFFF)
+
+    def after_load(self):
+        """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow."""
+        if getattr(self, "fused_update", None) is not None:
+            self.fused_update.sync(self.learning_rate)
+
+    def begin_iteration(self, iteration):
+        """Once per learning iteration, before the rollout and outside any captured graph: refresh what the collection kernels read."""
+        if getattr(self, "fused", None) is not None:
+            self.fused.refresh(iteration)
 
     def test_mode(self):
         self.actor_critic.eval()
@@ -38,6 +56,8 @@ class PPO:
         self.actor_critic.train()
 
     def act(self, obs, critic_obs):
+        if getattr(self, "fused", None) is not None and critic_obs is obs:
+            return self.fused.act(obs, self.storage)
         t = self.transition
         t.actions = self.actor_critic.act(obs).detach()
         t.values = self.actor_critic.evaluate(critic_obs).detach()
@@ -50,7 +70,17 @@ class PPO:
         t.critic_observations = t.observations if critic_obs is obs else critic_obs.clone()
         return t.actions
 
-    def process_env_step(self, rewards, dones, infos):
+    def process_env_step(self, rewards, dones, infos, stats=None):
+        """stats = (cur_ret, cur_len, fin) device tensors of the runner's episode bookkeeping: with the fused collector they are
+        updated in the same launch; returns True then (the caller skips its own bookkeeping)."""
+        if getattr(self, "fused", None) is not None and self.transition.actions is None:
+            if stats is None:   # a caller without episode bookkeeping of its own
+                if getattr(self, "_own_stats", None) is None:
+                    n = rewards.shape[0]
+                    self._own_stats = (torch.zeros(n, device=self.device), torch.zeros(n, device=self.device), torch.zeros(3, device=self.device))
+                stats = self._own_stats
+            self.fused.record(self.storage, rewards, dones, infos.get("time_outs"), self.gamma, *stats)
+            return True
         t = self.transition
         t.rewards = rewards.clone()
         t.dones = dones
@@ -59,6 +89,7 @@ class PPO:
         self.storage.add_transitions(t)
         t.clear()
         self.actor_critic.reset(dones)
+        return False
 
     def compute_returns(self, last_critic_obs):
         last_values = self.actor_critic.evaluate(last_critic_obs).detach()
@@ -77,7 +108,25 @@ class PPO:
             g.copy_(flat[off:off + n].view_as(g))
             off += n
 
+    def _update_fused(self):
+        hp = dict(clip=self.clip_param, value_coef=self.value_loss_coef, entropy_coef=self.entropy_coef, clip_value=self.use_clipped_value_loss,
+                  desired_kl=self.desired_kl if self.desired_kl is not None else 0.0,
+                  adaptive=self.desired_kl is not None and self.schedule == "adaptive", max_grad_norm=self.max_grad_norm)
+        fu = self.fused_update
+        for (obs, _cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in \
+                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+            fu.minibatch(obs, actions, target_values.reshape(-1), advantages.reshape(-1), returns.reshape(-1), old_logp.reshape(-1), old_mu, old_sigma, hp)
+        st = fu.read_state()                      # the one host synchronisation of the update
+        self.learning_rate, self.last_kl = st["lr"], st["kl"]
+        for g in self.optimizer.param_groups:
+            g["lr"] = self.learning_rate
+        n = max(st["minibatches"], 1.0)
+        self.storage.clear()
+        return st["value_loss_sum"] / n, st["surrogate_loss_sum"] / n
+
     def update(self):
+        if getattr(self, "fused_update", None) is not None:
+            return self._update_fused()
         v_sum = torch.zeros((), device=self.device)
         s_sum = torch.zeros((), device=self.device)
         gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)

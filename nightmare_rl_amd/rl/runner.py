@@ -38,7 +38,10 @@ class OnPolicyRunner:
                 dist.broadcast(p.data, 0)
         self.alg = _CLASSES[self.cfg["algorithm_class_name"]](ac, device=device, **self.alg_cfg)
         self.num_steps_per_env, self.save_interval = self.cfg["num_steps_per_env"], self.cfg["save_interval"]
-        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs], [env.num_actions])
+        # the reference env announces num_privileged_obs = num_obs (env.py:34) but hands out no privileged observations (:317-319):
+        # the critic then sees the actor's observation, and a second copy of it in the storage would only cost bandwidth
+        has_priv = env.get_privileged_observations() is not None
+        self.alg.init_storage(env.num_envs, self.num_steps_per_env, [env.num_obs], [env.num_privileged_obs if has_priv else None], [env.num_actions])
         self.log_dir = log_dir
         self.tot_timesteps, self.tot_time, self.current_learning_iteration = 0, 0.0, 0
         self.history = []
@@ -79,16 +82,21 @@ class OnPolicyRunner:
                 o, priv_, rewards, dones, infos = env.step(actions)
                 o, rewards, dones = o.to(dev), rewards.to(dev), dones.to(dev)
                 co = priv_.to(dev) if priv_ is not None else o
-                alg.process_env_step(rewards, dones, infos)
-                cur_ret.add_(rewards)
-                cur_len.add_(1)
-                d = (dones > 0).float()
-                fin.add_(torch.stack([(cur_ret * d).sum(), (cur_len * d).sum(), d.sum()]))
-                cur_ret.mul_(1 - d)
-                cur_len.mul_(1 - d)
+                if not alg.process_env_step(rewards, dones, infos, stats=(cur_ret, cur_len, fin)):
+                    cur_ret.add_(rewards)
+                    cur_len.add_(1)
+                    d = (dones > 0).float()
+                    fin.add_(torch.stack([(cur_ret * d).sum(), (cur_len * d).sum(), d.sum()]))
+                    cur_ret.mul_(1 - d)
+                    cur_len.mul_(1 - d)
                 if "episode" in infos:
                     keys = sorted(infos["episode"])
-                    e = torch.stack([infos["episode"][k].float() for k in keys])
+                    if hasattr(env, "_ep_stats") and hasattr(env, "_stat_names"):   # one gather from the env's statistics buffer
+                        if state.get("ep_idx") is None:
+                            state["ep_idx"] = torch.tensor([env._stat_names.index(k[4:]) for k in keys], device=dev)
+                        e = env._ep_stats.index_select(0, state["ep_idx"])
+                    else:
+                        e = torch.stack([infos["episode"][k].float() for k in keys])
                     if ep_acc is None:
                         ep_acc = torch.zeros_like(e)
                     ep_acc.add_(e)
@@ -102,6 +110,8 @@ class OnPolicyRunner:
         ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else (None, None)
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()
+            if hasattr(alg, "begin_iteration"):
+                alg.begin_iteration(it)
             if on_gpu:
                 ev0.record()
             with torch.inference_mode():
@@ -185,6 +195,8 @@ class OnPolicyRunner:
         if load_optimizer:
             self.alg.optimizer.load_state_dict(d["optimizer_state_dict"])
         self.current_learning_iteration = d["iter"]
+        if hasattr(self.alg, "after_load"):
+            self.alg.after_load()
         return d["infos"]
 
     def get_inference_policy(self, device=None):
