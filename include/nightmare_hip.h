@@ -186,6 +186,10 @@ nm_nik* nm_nik_create(int32_t num_envs, int32_t device);
 void nm_nik_destroy(nm_nik* h);
 /* back to IdleState with the default pose (a fresh EngineNode). ids_host NULL = all envs. */
 int nm_nik_reset(nm_nik* h, const int32_t* ids_host, int32_t n, void* stream);
+/* state.cmd.gait (engine.py:297; the gait table :214-225): 0 'tripod' (default), 1 'ripple', 2 'wave'; ids_host NULL = all envs. Upstream the
+ * field sits on a Command object shared by every EngineNode (RobotState.cmd is a class attribute, :402-406) and EngineNode.update does not
+ * touch it; here it is per env. Takes effect like upstream: when WalkState is entered (:543) or the running step completes (:627). */
+int nm_nik_set_gait(nm_nik* h, const int32_t* ids_host, int32_t n, int32_t gait, void* stream);
 /* EngineNode.update(lin_speed, ang_speed, state, mode) (engine.py:710-715) for every env, one launch.
  *   lin_dev, ang_dev [N] f64 device: walk translation along +y (m/s) and yaw rate (rad/s) commands
  *   awake_dev, walk_dev [N] u8 device or NULL: state == 'awake' (else 'idle'), mode == 'walk' (else 'stand'); NULL = 1

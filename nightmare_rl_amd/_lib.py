@@ -12,7 +12,7 @@ EXPORTS = ["nm_default_config", "nm_reward_name", "nm_last_error", "nm_create", 
            "nm_step", "nm_step_physics", "nm_get_state", "nm_set_state", "nm_get_buffers", "nm_set_buffers",
            "nm_set_command_uniforms", "nm_get_feet_state", "nm_set_feet_state", "nm_get_counters", "nm_set_debug_buffer", "nm_policy_create", "nm_policy_destroy", "nm_policy_load", "nm_policy_forward", "nm_profile", "nm_set_ablation", "nm_gae", "nm_ppo_sample", "nm_ppo_record", "nm_ppo_create", "nm_ppo_destroy", "nm_ppo_num_params", "nm_ppo_sync_params", "nm_ppo_minibatch", "nm_ppo_copy_grad", "nm_ppo_get_state",
            "nm_set_observation_noise", "nm_set_noise_uniforms", "nm_set_state_record", "nm_get_state_record",
-           "nm_nik_create", "nm_nik_destroy", "nm_nik_reset", "nm_nik_update", "nm_nik_get_state"]
+           "nm_nik_create", "nm_nik_destroy", "nm_nik_reset", "nm_nik_set_gait", "nm_nik_update", "nm_nik_get_state"]
 
 
 class NmConfig(C.Structure):
@@ -89,6 +89,7 @@ def load():
     L.nm_nik_destroy.argtypes = [vp]
     L.nm_nik_destroy.restype = None
     L.nm_nik_reset.argtypes = [vp, vp, C.c_int32, vp]
+    L.nm_nik_set_gait.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     L.nm_nik_update.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
     L.nm_nik_get_state.argtypes = [vp, vp, vp, vp]
     _lib = L

@@ -2083,9 +2083,15 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
   nm_stamp(2);
   for (int e = 0; e < G; e++) {
     Sh<real>& sh = w.e[e];
+#if defined(NM_ENVCOST) && !defined(NM_EMUL)
+    const unsigned long long t_bc = __builtin_amdgcn_s_memtime();
+#endif
     if (!(ablate & 1)) stage_collide(sh, M, dropped, !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     if (ablate & 4) { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     stage_constraint(sh, w.jrow, M, last, (ablate & 2) != 0);
+#if defined(NM_ENVCOST) && !defined(NM_EMUL)
+    sh.nhop += (int)((__builtin_amdgcn_s_memtime() - t_bc) >> 4);   // measurement build: the hop counter carries this env's B+C cycles / 16
+#endif
     nm_stamp(8);
   }
   stage_integrate(w, M);

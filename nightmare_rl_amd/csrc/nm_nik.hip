@@ -21,7 +21,9 @@ constexpr double kStandH = 0.10, kSitH = 0.0;                       // engine.py
 constexpr double kKeepout = 0.03, kStepTime = 1.0, kStepHeight = 0.05;
 constexpr double kTAdj = 1.0, kTGetUp = 2.5, kTSit = 2.5;
 constexpr double kCX = 0.065, kFM = 0.13, kTB = 0.17;               // leg segment lengths
-constexpr int kNGait = 2;                                           // tripod: two half steps
+// gaits (engine.py:214-225): swing masks per step, bit l = leg l swings. 0 tripod, 1 ripple, 2 wave
+__constant__ unsigned char c_gait_mask[3][6] = {{0x15, 0x2A, 0, 0, 0, 0}, {0x11, 0x0A, 0x24, 0, 0, 0}, {0x01, 0x02, 0x04, 0x08, 0x10, 0x20}};
+__constant__ int c_gait_len[3] = {2, 3, 6};
 enum { IDLE, ADJ_GETUP, GETUP, SIT, ADJ_SIT, STAND, WALK };
 
 __constant__ double c_default_xy[6][2] = {{0.20, 0.20}, {0.26, 0.0}, {0.20, -0.20}, {-0.20, -0.20}, {-0.26, 0.0}, {-0.20, 0.20}};
@@ -34,6 +36,7 @@ __constant__ unsigned char c_pair[16][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 
 struct NikArgs {
   int N;
   int* fsm; int* step;
+  int* gait_cmd; int* gait_cur;      // state.cmd.gait (what the caller asked for) and WalkState._gait (taken over at step boundaries)
   double* t0; double* gss;
   double* pose; double* start; double* last;   // [N,18] each
   const double* lin; const double* ang;
@@ -74,7 +77,7 @@ __device__ inline double min16(double v) {
 }
 // where leg `l` stands in the line search for reduction x (engine.py:560-565): grounded legs are dragged back by the
 // rest of the half step, stepping legs sit at their ahead-of-time target
-__device__ inline void probe_xy(int l, bool stepping, double px, double py, double lin, double ang, double x, double gss, double& ox, double& oy) {
+__device__ inline void probe_xy(int l, bool stepping, double px, double py, double lin, double ang, double x, double gss, int kNGait, double& ox, double& oy) {
   if (stepping) {
     const double f = x * kStepTime;
     ox = c_default_xy[l][0]; oy = c_default_xy[l][1] + lin * f;
@@ -119,6 +122,9 @@ __global__ void __launch_bounds__(64) k_nik_update(NikArgs a) {
   const int leg = s < 6 ? s : 5;
   const bool isleg = live && s < 6;
   const int fsm = a.fsm[e], step = a.step[e];
+  const int gcur = a.gait_cur[e], gcmd = a.gait_cmd[e];
+  const int kNGait = c_gait_len[gcur];
+  const unsigned swingm = c_gait_mask[gcur][step];
   const double t0 = a.t0[e], gss = a.gss[e];
   const double lin = a.lin[e], ang = a.ang[e];
   const bool awake = a.awake ? a.awake[e] != 0 : true, walk = a.walk ? a.walk[e] != 0 : true;
@@ -129,7 +135,7 @@ __global__ void __launch_bounds__(64) k_nik_update(NikArgs a) {
   double out[3] = {P[0], P[1], P[2]};
   int nfsm = fsm;                                          // state entered this tick (engine.py:649-653)
   double ngss = gss;
-  int nstep = step;
+  int nstep = step, ngait = gcur;
   bool set_last = false;
   const double adv_t = a.now - t0;
   if (fsm == IDLE) {                                       // :414-431 (RobotState.pose is the default pose, never updated)
@@ -178,14 +184,14 @@ __global__ void __launch_bounds__(64) k_nik_update(NikArgs a) {
   {
     const int pi = c_pair[s][0], pj = c_pair[s][1];
     const double pix = prow[3 * pi], piy = prow[3 * pi + 1], pjx = prow[3 * pj], pjy = prow[3 * pj + 1];
-    const bool wi = (pi & 1) == step, wj = (pj & 1) == step;   // tripod: even legs swing in half step 0, odd legs in half step 1
+    const bool wi = (swingm >> pi) & 1, wj = (swingm >> pj) & 1;
     double red = 1.0;
     bool done = !walking;
     for (int it = 0; it < 10; it++) {
       if (__all(done)) break;
       double ix, iy, jx, jy;
-      probe_xy(pi, wi, pix, piy, lin, ang, red, gss, ix, iy);
-      probe_xy(pj, wj, pjx, pjy, lin, ang, red, gss, jx, jy);
+      probe_xy(pi, wi, pix, piy, lin, ang, red, gss, kNGait, ix, iy);
+      probe_xy(pj, wj, pjx, pjy, lin, ang, red, gss, kNGait, jx, jy);
       double dmin = seg_seg(ix, iy, c_offset_xy[pi][0], c_offset_xy[pi][1], jx, jy, c_offset_xy[pj][0], c_offset_xy[pj][1]);
       dmin = min16(s < 15 ? dmin : 1e30);
       double cost = kKeepout - dmin;
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(64) k_nik_update(NikArgs a) {
       }
     }
     if (walking) {
-      const bool swing = (leg & 1) == step;
+      const bool swing = (swingm >> leg) & 1;
       if (!swing) {
         const double m = red * (1.0 / a.fps) * 2 * kNGait;
         out[0] = P[0]; out[1] = P[1] - lin * m; out[2] = P[2];
@@ -216,17 +222,17 @@ __global__ void __launch_bounds__(64) k_nik_update(NikArgs a) {
         }
       }
       ngss = gss + kNGait / (kStepTime * a.fps);
-      if (ngss > 1) { ngss = 0; nstep = (step + 1) % kNGait; set_last = true; }
+      if (ngss > 1) { ngait = gcmd; ngss = 0; nstep = (step + 1) % c_gait_len[ngait]; set_last = true; }   // engine.py:626-629
     }
   }
   // ---- state entry (constructors of the FSM states)
   if (nfsm != fsm) {
     if (isleg && nfsm == STAND) { double* srow = a.start + (size_t)e * 18; for (int k = 0; k < 3; k++) srow[3 * leg + k] = P[k]; }
-    if (nfsm == WALK) { ngss = 0; nstep = 0; set_last = true; }
+    if (nfsm == WALK) { ngss = 0; nstep = 0; ngait = gcmd; set_last = true; }   // WalkState.__init__ (:539-543)
     if (live && s == 0) { a.fsm[e] = nfsm; a.t0[e] = a.now; }
   }
   if (isleg && set_last) { double* lrow = a.last + (size_t)e * 18; for (int k = 0; k < 3; k++) lrow[3 * leg + k] = P[k]; }
-  if (live && s == 0) { a.gss[e] = ngss; a.step[e] = nstep; }
+  if (live && s == 0) { a.gss[e] = ngss; a.step[e] = nstep; a.gait_cur[e] = ngait; }
   if (isleg) {
     double* wrow = a.pose + (size_t)e * 18;
     for (int k = 0; k < 3; k++) wrow[3 * leg + k] = out[k];
@@ -243,11 +249,15 @@ __global__ void __launch_bounds__(64) k_nik_update(NikArgs a) {
   }
 }
 
+__global__ void k_nik_set_gait(NikArgs a, const int* ids, int n, int gait) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a.gait_cmd[ids ? ids[i] : i] = gait;
+}
 __global__ void k_nik_reset(NikArgs a, const int* ids, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int e = ids ? ids[i] : i;
-  a.fsm[e] = IDLE; a.step[e] = 0; a.t0[e] = 0; a.gss[e] = 0;
+  a.fsm[e] = IDLE; a.step[e] = 0; a.t0[e] = 0; a.gss[e] = 0; a.gait_cur[e] = a.gait_cmd[e];
   for (int l = 0; l < 6; l++) {
     const double d[3] = {c_default_xy[l][0], c_default_xy[l][1], -kStandH};
     for (int k = 0; k < 3; k++) { a.pose[(size_t)e * 18 + 3 * l + k] = d[k]; a.start[(size_t)e * 18 + 3 * l + k] = d[k]; a.last[(size_t)e * 18 + 3 * l + k] = d[k]; }
@@ -273,7 +283,9 @@ extern "C" nm_nik* nm_nik_create(int32_t num_envs, int32_t device) {
   bool ok = hipMalloc((void**)&h->a.fsm, N * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->a.step, N * sizeof(int)) == hipSuccess &&
             hipMalloc((void**)&h->a.t0, N * sizeof(double)) == hipSuccess && hipMalloc((void**)&h->a.gss, N * sizeof(double)) == hipSuccess &&
             hipMalloc((void**)&h->a.pose, N * 18 * sizeof(double)) == hipSuccess && hipMalloc((void**)&h->a.start, N * 18 * sizeof(double)) == hipSuccess &&
-            hipMalloc((void**)&h->a.last, N * 18 * sizeof(double)) == hipSuccess && hipMalloc((void**)&h->ids, N * sizeof(int)) == hipSuccess;
+            hipMalloc((void**)&h->a.last, N * 18 * sizeof(double)) == hipSuccess && hipMalloc((void**)&h->ids, N * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&h->a.gait_cmd, N * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->a.gait_cur, N * sizeof(int)) == hipSuccess;
+  if (ok) ok = hipMemset(h->a.gait_cmd, 0, N * sizeof(int)) == hipSuccess;
   if (!ok) { nm_policy_set_error("nm_nik_create: hipMalloc failed"); delete h; return nullptr; }
   hipLaunchKernelGGL(k_nik_reset, dim3((num_envs + 255) / 256), dim3(256), 0, 0, h->a, (const int*)nullptr, num_envs);
   if (hipDeviceSynchronize() != hipSuccess) { nm_policy_set_error("nm_nik_create: reset kernel failed"); delete h; return nullptr; }
@@ -283,7 +295,7 @@ extern "C" nm_nik* nm_nik_create(int32_t num_envs, int32_t device) {
 extern "C" void nm_nik_destroy(nm_nik* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  void* p[] = {h->a.fsm, h->a.step, h->a.t0, h->a.gss, h->a.pose, h->a.start, h->a.last, h->ids};
+  void* p[] = {h->a.fsm, h->a.step, h->a.t0, h->a.gss, h->a.pose, h->a.start, h->a.last, h->ids, h->a.gait_cmd, h->a.gait_cur};
   for (void* q : p) if (q) (void)hipFree(q);
   delete h;
 }
@@ -301,6 +313,25 @@ extern "C" int nm_nik_reset(nm_nik* h, const int32_t* ids_host, int32_t n, void*
   hipLaunchKernelGGL(k_nik_reset, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->a, ids_host ? (const int*)h->ids : (const int*)nullptr, n);
   NIK_CHECK(hipGetLastError(), "nm_nik_reset: launch failed");
   if (ids_host) NIK_CHECK(hipStreamSynchronize((hipStream_t)stream), "nm_nik_reset: sync failed");   // ids_host may be reused by the caller
+  return 0;
+}
+
+// state.cmd.gait of the listed engines (engine.py:297): 0 'tripod' (the default), 1 'ripple', 2 'wave' (engine.py:214-225). Like upstream
+// a walking engine takes the new gait over when its current step completes (:627), a starting one when WalkState is built (:543).
+extern "C" int nm_nik_set_gait(nm_nik* h, const int32_t* ids_host, int32_t n, int32_t gait, void* stream) {
+  if (!h) return nm_policy_set_error("nm_nik_set_gait: null handle");
+  if (gait < 0 || gait > 2) return nm_policy_set_error("nm_nik_set_gait: gait is 0 (tripod), 1 (ripple) or 2 (wave)");
+  NIK_CHECK(hipSetDevice(h->device), "nm_nik_set_gait: hipSetDevice failed");
+  if (!ids_host) n = h->N;
+  if (n <= 0) return 0;
+  if (ids_host) {
+    if (n > h->N) return nm_policy_set_error("nm_nik_set_gait: more ids than envs");
+    for (int i = 0; i < n; i++) if (ids_host[i] < 0 || ids_host[i] >= h->N) return nm_policy_set_error("nm_nik_set_gait: env id out of range");
+    NIK_CHECK(hipMemcpyAsync(h->ids, ids_host, (size_t)n * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream), "nm_nik_set_gait: copy failed");
+  }
+  hipLaunchKernelGGL(k_nik_set_gait, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->a, ids_host ? (const int*)h->ids : (const int*)nullptr, n, gait);
+  NIK_CHECK(hipGetLastError(), "nm_nik_set_gait: launch failed");
+  if (ids_host) NIK_CHECK(hipStreamSynchronize((hipStream_t)stream), "nm_nik_set_gait: sync failed");
   return 0;
 }
 

@@ -36,6 +36,42 @@ def rollout(fps, cmds, dt, ticks, mode="walk"):
     return np.array(ts), np.array(inp), np.array(out)
 
 
+def main_gaits():
+    """ripple / wave gaits (engine.py:214-225) and a gait change while walking. EngineNode.update has no gait argument: upstream the
+    gait is state.cmd.gait, a field of a Command object that every EngineNode shares (RobotState.cmd is a class attribute, :402-406);
+    it is read when WalkState is built (:543) and again whenever a step completes (:627)."""
+    fps = 51.0
+    data = {}
+
+    def rollout_gait(schedule, ticks, cmd):
+        ref.config.ENGINE_FPS = fps
+        with contextlib.redirect_stdout(io.StringIO()):
+            node = ref.EngineNode()
+        node._robot_state.cmd.gait = "tripod"
+        out, gaits = [], []
+        for k in range(ticks):
+            if k in schedule:
+                node._robot_state.cmd.gait = schedule[k]
+            ref.set_time_s(k / fps)
+            with contextlib.redirect_stdout(io.StringIO()):
+                out.append(np.array(node.update(cmd[0], cmd[1], "awake", "walk"), dtype=np.float64))
+            gaits.append(["tripod", "ripple", "wave"].index(node._robot_state.cmd.gait))
+        node._robot_state.cmd.gait = "tripod"        # the Command object is shared by every later EngineNode
+        return np.array(out), np.array(gaits)
+
+    for name in ("ripple", "wave"):
+        o, gsel = rollout_gait({0: name}, 700, (0.06, 0.25))
+        data[name + "_out"], data[name + "_gait"] = o, gsel
+    o, gsel = rollout_gait({0: "tripod", 300: "wave", 520: "ripple", 700: "tripod"}, 900, (-0.05, -0.3))
+    data["switch_out"], data["switch_gait"] = o, gsel
+    data["fps"] = np.array(fps)
+    data["cmd_fixed"] = np.array([0.06, 0.25])
+    data["cmd_switch"] = np.array([-0.05, -0.3])
+    path = os.path.join(ROOT, "tests", "golden", "nikengine_gaits.npz")
+    np.savez_compressed(path, **data)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
 def main():
     rng = np.random.default_rng(0)
     data = {}
@@ -77,4 +113,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "gaits":
+        main_gaits()
+    else:
+        main()

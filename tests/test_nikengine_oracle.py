@@ -60,3 +60,25 @@ def test_stand_mode():
     g = _g()
     out = _replay(51.0, g["stand_in"], g["stand_t"], walk=False)
     np.testing.assert_allclose(out, g["stand_out"], atol=1e-10)
+
+
+def _replay_gaits(out_ref, gait_sel, cmd, fps):
+    from oracle import nik_oracle as nk
+    e = nk.Engine(engine_fps=fps)
+    names = ["tripod", "ripple", "wave"]
+    res = []
+    for k in range(len(out_ref)):
+        e.gait_cmd = names[int(gait_sel[k])]
+        res.append(e.update(cmd[0], cmd[1], awake=True, walk=True, now=k / fps))
+    return np.array(res)
+
+
+def test_ripple_and_wave_gaits_and_a_gait_change_while_walking():
+    g = load_golden("nikengine_gaits.npz")
+    fps = float(g["fps"])
+    for name in ("ripple", "wave"):
+        out = _replay_gaits(g[name + "_out"], g[name + "_gait"], g["cmd_fixed"], fps)
+        np.testing.assert_allclose(out, g[name + "_out"], atol=1e-10, err_msg=name)
+    out = _replay_gaits(g["switch_out"], g["switch_gait"], g["cmd_switch"], fps)
+    np.testing.assert_allclose(out, g["switch_out"], atol=1e-10)
+    assert np.abs(g["ripple_out"][400:] - g["wave_out"][400:]).max() > 1e-2       # the gaits really differ
