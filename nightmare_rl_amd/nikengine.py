@@ -13,6 +13,7 @@ import torch
 
 from . import _lib
 
+GAIT_NAMES = ["tripod", "ripple", "wave"]      # engine.py:214-225
 FSM_NAMES = ["idle", "adjust_get_up", "get_up", "sit", "adjust_sit", "stand", "walk"]
 
 
@@ -90,6 +91,19 @@ class EngineNode:
         if self.num_envs == 1 and not torch.is_tensor(lin_speed):
             return self.angles[0].double().cpu().numpy()
         return self.angles
+
+    def set_gait(self, gait, env_ids=None):
+        """state.cmd.gait (engine.py:297) of all or the listed engines: 'tripod' (default), 'ripple' or 'wave'. A walking engine takes
+        the new gait over when its current step completes (:627), a starting one when it begins to walk (:543). Upstream the Command
+        object is a class attribute shared by every EngineNode of the process (:402-406); here it is per env."""
+        if gait not in GAIT_NAMES:
+            raise ValueError("gait must be one of %s" % GAIT_NAMES)
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        if env_ids is None:
+            _lib.check(self.L.nm_nik_set_gait(self.h, None, self.num_envs, GAIT_NAMES.index(gait), stream))
+        else:
+            ids = np.ascontiguousarray(torch.as_tensor(env_ids).cpu().numpy(), np.int32)
+            _lib.check(self.L.nm_nik_set_gait(self.h, ids.ctypes.data_as(C.c_void_p), len(ids), GAIT_NAMES.index(gait), stream))
 
     def reset(self, env_ids=None):
         stream = torch.cuda.current_stream(self.device).cuda_stream

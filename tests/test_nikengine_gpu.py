@@ -69,6 +69,36 @@ def test_ik_table_through_the_kernel_matches_oracle_batch():
     nk.config.ENGINE_FPS = 51.0
 
 
+def test_ripple_and_wave_gaits_and_a_gait_change_while_walking():
+    """Reference-generated golden (make_nik_goldens.py gaits): one env per schedule in ONE batched engine, so the per-env gait state
+    is exercised too (env 0 ripple, env 1 wave, env 2 untouched tripod as the control against the plain walk golden)."""
+    import torch
+    from nightmare_rl_amd import nikengine as nk
+    g = load_golden("nikengine_gaits.npz")
+    fps = float(g["fps"])
+    nk.config.ENGINE_FPS = fps
+    eng = nk.EngineNode(2, dtype=torch.float64)
+    eng.set_gait("ripple", [0])
+    eng.set_gait("wave", [1])
+    lin = torch.full((2,), float(g["cmd_fixed"][0]), dtype=torch.float64)
+    ang = torch.full((2,), float(g["cmd_fixed"][1]), dtype=torch.float64)
+    n = len(g["ripple_out"])
+    out = np.array([eng.update(lin, ang, time_s=k / fps).cpu().numpy() for k in range(n)])
+    np.testing.assert_allclose(out[:, 0], g["ripple_out"], atol=TOL)
+    np.testing.assert_allclose(out[:, 1], g["wave_out"], atol=TOL)
+    eng = nk.EngineNode(1, dtype=torch.float64)
+    sel, names, res = g["switch_gait"], nk.GAIT_NAMES, []
+    for k in range(len(sel)):
+        if k == 0 or sel[k] != sel[k - 1]:
+            eng.set_gait(names[int(sel[k])])
+        nk.set_time_s(k / fps)
+        res.append(eng.update(float(g["cmd_switch"][0]), float(g["cmd_switch"][1])).copy())
+    np.testing.assert_allclose(np.array(res), g["switch_out"], atol=TOL)
+    with pytest.raises(ValueError):
+        eng.set_gait("gallop")
+    nk.config.ENGINE_FPS = 51.0
+
+
 def test_float32_output_and_errors():
     import torch
     from nightmare_rl_amd import nikengine as nk, _lib
