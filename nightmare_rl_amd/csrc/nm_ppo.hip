@@ -284,16 +284,37 @@ __global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restr
 }
 // gradient of every real parameter: sum of the workgroups' partial gradients at its merged position (std: from the scalar tail,
 // plus the entropy bonus -c_e * d(sum_j log std_j)/d(std_j))
-__global__ void k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
+constexpr int kRedParams = 64, kRedWaves = 8;
+__global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
                              const float* __restrict__ flat, float ent_coef, float* __restrict__ grad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  const int m = map[i];
-  const int idx = m >= 0 ? m : gtotal + (-m - 1);
+  // a block sums 64 consecutive parameters: wave w takes workgroups w, w + 8, ... (independent loads, 256 B runs), LDS joins the waves
+  // in a fixed order - the result does not depend on scheduling
+  __shared__ float part[kRedWaves][kRedParams];
+  const int lane = threadIdx.x & 63, w0 = threadIdx.x >> 6;
+  const int i = blockIdx.x * kRedParams + lane;
   float g = 0.0f;
-  for (int w = 0; w < nwg; w++) g += partial[(size_t)w * stride + idx];
-  if (m < 0) g -= ent_coef / flat[i];
-  grad[i] = g;
+  int m = 0;
+  if (i < n) {
+    m = map[i];
+    const float* P = partial + (m >= 0 ? m : gtotal + (-m - 1));
+    float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+    int w = w0;
+    for (; w + 3 * kRedWaves < nwg; w += 4 * kRedWaves) {
+      g0 += P[(size_t)w * stride]; g1 += P[(size_t)(w + kRedWaves) * stride];
+      g2 += P[(size_t)(w + 2 * kRedWaves) * stride]; g3 += P[(size_t)(w + 3 * kRedWaves) * stride];
+    }
+    for (; w < nwg; w += kRedWaves) g0 += P[(size_t)w * stride];
+    g = (g0 + g1) + (g2 + g3);
+  }
+  part[w0][lane] = g;
+  __syncthreads();
+  if (w0 == 0 && i < n) {
+    g = 0.0f;
+#pragma unroll
+    for (int w = 0; w < kRedWaves; w++) g += part[w][lane];
+    if (m < 0) g -= ent_coef / flat[i];
+    grad[i] = g;
+  }
 }
 // state: [0] lr [1] step [2] last kl [3] sum of value losses [4] sum of surrogate losses [5] mini-batches [6] clip coefficient [7] grad norm
 __global__ void k_ppo_scalars(const float* __restrict__ partial, int nwg, int stride, int gtotal, const float* __restrict__ grad, int n, float inv_B,
@@ -476,13 +497,13 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
   if (n_obs != h->net.Kr[0]) return nm_policy_set_error("nm_ppo_minibatch: observation width does not match the network");
   PPO_CHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256;
+  const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + kRedParams - 1) / kRedParams;
   if (phase == 0 || phase == 1) {     // 1: gradient only
     PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value};
     const int ntiles = (B + kRows - 1) / kRows, grid = ntiles < h->nwg ? ntiles : h->nwg;
     if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
     hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
-    hipLaunchKernelGGL(k_ppo_reduce, dim3(nb), dim3(256), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, h->grad);
+    hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, h->grad);
   }
   if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced nm_ppo_grad()
     hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nwg, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,

@@ -43,15 +43,23 @@ __device__ __forceinline__ float u24(uint64_t seed, uint64_t a, uint64_t b) {   
   x ^= x >> 31;
   return ((float)(uint32_t)(x >> 40) + 1.0f) * (1.0f / 16777216.0f);
 }
-__global__ void k_ppo_sample(const float* __restrict__ net_out, const float* __restrict__ std, const float* __restrict__ obs, int N, int A, int n_obs,
+// 16 lanes per env: lane j < ceil(A/2) draws the action pair (2j, 2j+1) (Box-Muller: two normals per pair of uniforms), the
+// log-probability is summed over the 16 lanes, and the block copies its 16 envs' observations as one contiguous run.
+constexpr int kSampleEnvs = 16;    // envs per 256-thread block
+__global__ void __launch_bounds__(256) k_ppo_sample(const float* __restrict__ net_out, const float* __restrict__ std, const float* __restrict__ obs, int N, int A, int n_obs,
                              uint64_t seed, const int64_t* __restrict__ iter_dev, int step, float* __restrict__ actions, float* __restrict__ logp,
                              float* __restrict__ values, float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ obs_store) {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= N) return;
-  const uint64_t ctr = (uint64_t)iter_dev[0] * 4096ull + (uint64_t)step;
-  const float* o = net_out + (size_t)e * (A + 1);
+  const int e0 = blockIdx.x * kSampleEnvs;
+  if (obs_store) {
+    const size_t base = (size_t)e0 * n_obs;
+    const int cnt = min(kSampleEnvs, N - e0) * n_obs;
+    for (int i = threadIdx.x; i < cnt; i += 256) obs_store[base + i] = obs[base + i];
+  }
+  const int e = e0 + (threadIdx.x >> 4), j = 2 * (threadIdx.x & 15);
   float lp = 0.0f;
-  for (int j = 0; j < A; j += 2) {   // Box-Muller: two normals per pair of uniforms
+  if (e < N && j < A) {
+    const uint64_t ctr = (uint64_t)iter_dev[0] * 4096ull + (uint64_t)step;
+    const float* o = net_out + (size_t)e * (A + 1);
     const float u1 = u24(seed, (uint64_t)e * 64 + j, ctr), u2 = u24(seed, (uint64_t)e * 64 + j + 1, ctr);
     const float rad = sqrtf(-2.0f * __logf(u1));
     float sn, cs;
@@ -59,23 +67,21 @@ __global__ void k_ppo_sample(const float* __restrict__ net_out, const float* __r
     const float z[2] = {rad * cs, rad * sn};
     for (int h = 0; h < 2 && j + h < A; h++) {
       const float m = o[j + h], sd = std[j + h];
-      const float a = m + sd * z[h];
-      actions[(size_t)e * A + j + h] = a;
+      actions[(size_t)e * A + j + h] = m + sd * z[h];
       mu[(size_t)e * A + j + h] = m;
       sigma[(size_t)e * A + j + h] = sd;
       lp += -0.5f * z[h] * z[h] - __logf(sd) - 0.9189385332046727f;   // Normal.log_prob: -(a-m)^2/(2 sd^2) - log sd - log sqrt(2 pi)
     }
+    if (j == 0) values[e] = o[A];
   }
-  logp[e] = lp;
-  values[e] = o[A];
-  if (obs_store)
-    for (int k = 0; k < n_obs; k++) obs_store[(size_t)e * n_obs + k] = obs[(size_t)e * n_obs + k];
+  lp += __shfl_xor(lp, 1); lp += __shfl_xor(lp, 2); lp += __shfl_xor(lp, 4); lp += __shfl_xor(lp, 8);
+  if (e < N && j == 0) logp[e] = lp;
 }
 extern "C" int nm_ppo_sample(const float* net_out, const float* std, const float* obs, int32_t N, int32_t A, int32_t n_obs, uint64_t seed,
                              const int64_t* iter_dev, int32_t step, float* actions, float* logp, float* values, float* mu, float* sigma, float* obs_store,
                              void* stream) {
-  if (!net_out || !std || !iter_dev || !actions || !logp || !values || !mu || !sigma || N <= 0 || A <= 0 || A > 62) return nm_policy_set_error("nm_ppo_sample: bad argument");
-  hipLaunchKernelGGL(k_ppo_sample, dim3((N + 127) / 128), dim3(128), 0, (hipStream_t)stream, net_out, std, obs, N, A, n_obs, seed, iter_dev, step, actions,
+  if (!net_out || !std || !iter_dev || !actions || !logp || !values || !mu || !sigma || N <= 0 || A <= 0 || A > 32) return nm_policy_set_error("nm_ppo_sample: bad argument (1..32 actions)");
+  hipLaunchKernelGGL(k_ppo_sample, dim3((N + kSampleEnvs - 1) / kSampleEnvs), dim3(256), 0, (hipStream_t)stream, net_out, std, obs, N, A, n_obs, seed, iter_dev, step, actions,
                      logp, values, mu, sigma, obs_store);
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_sample: launch failed");
   return 0;

@@ -21,7 +21,7 @@ class FusedCollector:
             return False
         a = [m for m in ac.actor if isinstance(m, nn.Linear)]
         c = [m for m in ac.critic if isinstance(m, nn.Linear)]
-        if len(a) != len(c) or len(a) > 4 or a[0].in_features != c[0].in_features or c[-1].out_features != 1 or a[-1].out_features > 62:
+        if len(a) != len(c) or len(a) > 4 or a[0].in_features != c[0].in_features or c[-1].out_features != 1 or a[-1].out_features > 32:
             return False
         return all(x.out_features + y.out_features <= 256 for x, y in zip(a, c)) and a[0].in_features <= 256
 
