@@ -20,6 +20,8 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
+#include <utility>
 #include <vector>
 
 #include "../../include/nightmare_hip.h"
@@ -38,6 +40,7 @@ constexpr int kThreads = 512, kWaves = 8;
 constexpr int kSlots = 16;                 // dW tiles a wave can own
 constexpr int kMaxA = 32;                  // actions (<=)
 constexpr int kNS = 40;                    // per-workgroup scalars: dstd[32], kl, surrogate, value loss, count, pad
+constexpr int kFastWaves = 4, kFastSlots = 32;
 
 struct PpoNet {
   int n_layers;
@@ -49,6 +52,7 @@ struct PpoNet {
   const f32x4* pf[kL];         // forward packing   [O tile][k group][lane]
   const f32x4* pb[kL];         // backward packing  [K tile][o group][lane]
   int slot[kWaves][kSlots];    // dW tiles of wave w: layer | o tile << 4 | k tile << 8, -1 = none (tile g of the network goes to wave g % 8)
+  int slot2[kFastWaves][kFastSlots];   // fast kernel: dW tiles of wave w, slot order = layer by layer: o tile | k tile << 4, -1 = none
 };
 struct PpoBatch {
   const float *obs, *actions, *old_mu, *old_sigma, *old_logp, *adv, *ret, *tval, *std;
@@ -257,24 +261,308 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
   }
 }
 
-// merged [Op x Kp] matrices (bias in column Kr) -> the two MFMA packings
-__global__ void k_ppo_pack(const float* __restrict__ Wm, f32x4* __restrict__ pf, f32x4* __restrict__ pb, int Op, int Kp) {
+
+// ------------------------------------------------------------------------------------------------ fast path
+// For the reference's network shape (three hidden layers, known at compile time) the mini-batch runs through k_ppo_fwdbwd_fast:
+//   * a wave owns 16 rows from observation to deltas; activations and deltas never leave its registers. Every product is computed
+//     transposed, Y' = W X': the weights are the A operand (straight from L2, 16 B per lane per 4 MFMAs), the activations the B
+//     operand, and the result lands as lane (row r, q) <- features 16 t + 4 q + reg of tile t - exactly the B-operand layout of the
+//     next layer (feature order inside a k-step is free as long as the packed weights use the same one) and of dX = W' D'.
+//     No LDS, no barrier, no cross-wave dependency in forward, loss head and dX.
+//   * tiles of the merged matrices that hold no parameter (actor x critic blocks) are skipped at compile time: 85 of 109.
+//   * only dW needs the batch on the k axis: per layer the four waves of a workgroup park their transposed delta / activation tiles
+//     in LDS (conflict-free b32 writes, b128 reads), one barrier, then each wave accumulates its share of the layer's dW tiles over
+//     the workgroup's 64 rows; two buffers alternate between layers, so that barrier is the only one.
+//   One workgroup (4 waves, 1 per SIMD, 512 registers each) per CU.
+template <int N, class F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl<N>(f, std::make_integer_sequence<int, N>{}); }
+
+template <int I_, int A1, int A2, int A3, int AO, int C1, int C2, int C3>
+struct Shape4 {
+  static constexpr int NL = 4;
+  static constexpr __host__ __device__ int ain(int l) { return l == 0 ? I_ : l == 1 ? A1 : l == 2 ? A2 : A3; }
+  static constexpr __host__ __device__ int cin(int l) { return l == 0 ? I_ : l == 1 ? C1 : l == 2 ? C2 : C3; }
+  static constexpr __host__ __device__ int aout(int l) { return l == 0 ? A1 : l == 1 ? A2 : l == 2 ? A3 : AO; }
+  static constexpr __host__ __device__ int cout(int l) { return l == 0 ? C1 : l == 1 ? C2 : l == 2 ? C3 : 1; }
+  static constexpr __host__ __device__ int Kr(int l) { return l == 0 ? I_ : ain(l) + cin(l); }
+  static constexpr __host__ __device__ int Or(int l) { return aout(l) + cout(l); }
+  static constexpr __host__ __device__ int up16(int x) { return (x + 15) & ~15; }
+  // padded width of the input of layer l (l = NL: of the network output) - the rule of nm_ppo_create
+  static constexpr __host__ __device__ int P(int l) { return l == NL ? up16(Or(NL - 1)) : up16(Kr(l) + 1); }
+  static constexpr __host__ __device__ int maxT() { int m = 0; for (int l = 0; l <= NL; l++) m = P(l) / 16 > m ? P(l) / 16 : m; return m; }
+  // does tile (o tile, k tile) of merged layer l hold a parameter? (positions as nm_ppo_create's map)
+  static constexpr __host__ __device__ bool nz(int l, int to, int tk) {
+    const int o0 = 16 * to, o1 = o0 + 16, k0 = 16 * tk, k1 = k0 + 16;
+    const int cc0 = l == 0 ? 0 : ain(l), cc1 = cc0 + cin(l);
+    const bool actor = o0 < aout(l) && k0 < ain(l);
+    const bool critic = o0 < Or(l) && o1 > aout(l) && k0 < cc1 && k1 > cc0;
+    const bool bias = o0 < Or(l) && k0 <= Kr(l) && Kr(l) < k1;
+    return actor || critic || bias;
+  }
+  static constexpr __host__ __device__ int ntiles(int l) { int n = 0; for (int to = 0; to < P(l + 1) / 16; to++) for (int tk = 0; tk < P(l) / 16; tk++) n += nz(l, to, tk); return n; }
+  static constexpr __host__ __device__ int slots(int l) { return (ntiles(l) + kFastWaves - 1) / kFastWaves; }
+  static constexpr __host__ __device__ int slotbase(int l) { int n = 0; for (int i = 0; i < l; i++) n += slots(i); return n; }
+  static constexpr __host__ __device__ int nslots() { return slotbase(NL); }
+  // floats of exchange buffer b (layers of parity b)
+  static constexpr __host__ __device__ int xfloats(int b) { int m = 0; for (int l = b; l < NL; l += 2) { const int n = (P(l) + P(l + 1)) / 16 * kFastWaves * 320; m = n > m ? n : m; } return m; }
+};
+typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+
+template <class S>
+__global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net, PpoBatch bt, float* __restrict__ partial) {
+  constexpr int NL = S::NL, MT = S::maxT(), PO = S::P(NL) / 16, AO = S::aout(NL - 1), I = S::Kr(0);
+  constexpr int kXT = 20, kTileF = 16 * kXT;       // an exchange tile: 16 features x (16 rows + 4 pad) floats
+  static_assert(S::nslots() <= kFastSlots && AO + 1 <= 32 && PO <= 2, "shape outside the fast kernel's limits");
+  __shared__ __attribute__((aligned(16))) float xb0[S::xfloats(0)];
+  __shared__ __attribute__((aligned(16))) float xb1[S::xfloats(1)];
+  __shared__ float hsum[kFastWaves][40];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+  const int prow = (r & 3) * 4 + (r >> 2);         // rows are parked as [row mod 4][row div 4]: one b128 read = rows 4 s + q', s = 0..3
+  f32x4 gw[S::nslots()];
+  sfor<S::nslots()>([&](auto i) { gw[i] = f32x4{0, 0, 0, 0}; });
+  float a_dstd[PO][4], a_kl = 0.0f, a_surr = 0.0f, a_vl = 0.0f;
+  float sdv[PO][4];
+  sfor<PO>([&](auto T) {
+    constexpr int t = T;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) { a_dstd[t][reg] = 0.0f; const int f = 16 * t + 4 * q + reg; sdv[t][reg] = f < AO ? bt.std[f] : 1.0f; }
+  });
+  const int npass = (bt.B + 16 * kFastWaves - 1) / (16 * kFastWaves);
+  for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    const int row = (pass * kFastWaves + w) * 16 + r;
+    const bool live = row < bt.B;
+    int wlane = lane;          // opaque per pass: the 135 weight fragments are re-read from L2 every pass, not hoisted out of the loop into 540 registers
+    asm volatile("" : "+v"(wlane));
+    const size_t lrow = live ? row : 0;
+    f32x4 a[NL][MT], d[2][MT], out[PO];
+    // ---- observation tile (B operand of layer 0) and the head's per-row data (used much later: their latency hides behind the forward)
+    sfor<S::P(0) / 16>([&](auto T) {
+      constexpr int t = T;
+      f32x4 v = {0, 0, 0, 0};
+      if constexpr (16 * t + 16 <= I) {
+        v = *reinterpret_cast<const f32x4u*>(bt.obs + lrow * I + 16 * t + 4 * q);
+      } else {
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) { const int f = 16 * t + 4 * q + reg; v[reg] = f < I ? bt.obs[lrow * I + f] : (f == I ? 1.0f : 0.0f); }
+      }
+      if (!live) v = f32x4{0, 0, 0, 0};
+      a[0][t] = v;
+    });
+    f32x4 h_act[PO], h_omu[PO], h_osd[PO];
+    sfor<PO>([&](auto T) {
+      constexpr int t = T;
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int f = 16 * t + 4 * q + reg;
+        const bool on = f < AO;
+        h_act[t][reg] = on ? bt.actions[lrow * AO + f] : 0.0f;
+        h_omu[t][reg] = on ? bt.old_mu[lrow * AO + f] : 0.0f;
+        h_osd[t][reg] = on ? bt.old_sigma[lrow * AO + f] : 1.0f;
+      }
+    });
+    const float h_adv = bt.adv[lrow], h_olp = bt.old_logp[lrow], h_ret = bt.ret[lrow], h_tv = bt.tval[lrow];
+    // ---- forward
+    sfor<NL>([&](auto L) {
+      constexpr int l = L, nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
+      constexpr bool last = l == NL - 1;
+      const f32x4* __restrict__ wp = net.pf[l] + wlane;
+      sfor<nto>([&](auto TO) {
+        constexpr int to = TO;
+        f32x4 acc = {0, 0, 0, 0};
+        sfor<nkt>([&](auto TK) {
+          constexpr int tk = TK;
+          if constexpr (S::nz(l, to, tk)) {
+            const f32x4 wv = wp[(to * nkt + tk) * 64];
+#pragma unroll
+            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], a[l][tk][j], acc, 0, 0, 0);
+          }
+        });
+        if constexpr (last) {
+          out[to] = acc;
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) {
+            const int col = 16 * to + 4 * q + reg;
+            const float v = acc[reg];
+            a[l + 1][to][reg] = col < S::Or(l) ? (v > 0.0f ? v : __expf(v) - 1.0f) : (col == S::Or(l) ? 1.0f : 0.0f);   // ELU | bias carrier | padding
+          }
+        }
+      });
+    });
+    // ---- loss head: lane (row r, q) holds outputs 16 t + 4 q + reg; per-row sums cross the four q lanes
+    {
+      float lp = 0.0f, kl = 0.0f;
+      sfor<PO>([&](auto T) {
+        constexpr int t = T;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int f = 16 * t + 4 * q + reg;
+          if (f < AO) {
+            const float mu = out[t][reg], sd = sdv[t][reg], osd = h_osd[t][reg], omu = h_omu[t][reg];
+            const float z = (h_act[t][reg] - mu) / sd;
+            lp += -0.5f * z * z - __logf(sd) - 0.9189385332046727f;
+            kl += __logf(sd / osd + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) / (2.0f * sd * sd) - 0.5f;
+          }
+        }
+      });
+      lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+      float dlogp = 0.0f;      // d(surrogate)/d(logp) * (1/B)
+      if (live) {
+        const float ratio = __expf(lp - h_olp);
+        const float s1 = -h_adv * ratio, rc = fminf(fmaxf(ratio, 1.0f - bt.clip), 1.0f + bt.clip), s2 = -h_adv * rc;
+        const bool inside = ratio > 1.0f - bt.clip && ratio < 1.0f + bt.clip;
+        // torch.max(s1, s2).backward(): the larger branch gets the gradient, a tie splits it; the clipped branch has zero slope outside the range
+        const float g1 = s1 > s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f), g2 = 1.0f - g1;
+        dlogp = (g1 * (-h_adv * ratio) + g2 * (inside ? -h_adv * ratio : 0.0f)) * bt.inv_B;
+        a_kl += kl;
+        if (q == 0) a_surr += fmaxf(s1, s2);
+      }
+      sfor<PO>([&](auto T) {
+        constexpr int t = T;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int f = 16 * t + 4 * q + reg;
+          float dd = 0.0f;
+          if (live && f < AO) {
+            const float mu = out[t][reg], sd = sdv[t][reg], am = h_act[t][reg] - mu;
+            dd = dlogp * am / (sd * sd);
+            a_dstd[t][reg] += dlogp * (am * am / (sd * sd * sd) - 1.0f / sd);
+          } else if (live && f == AO) {
+            const float v = out[t][reg];
+            float dv, vl;
+            if (bt.clip_value) {
+              const float dvt = v - h_tv, vc = h_tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
+              const float l1 = (v - h_ret) * (v - h_ret), l2 = (vc - h_ret) * (vc - h_ret);
+              const bool in2 = dvt > -bt.clip && dvt < bt.clip;
+              const float h1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), h2 = 1.0f - h1;
+              vl = fmaxf(l1, l2);
+              dv = h1 * 2.0f * (v - h_ret) + h2 * (in2 ? 2.0f * (vc - h_ret) : 0.0f);
+            } else {
+              vl = (h_ret - v) * (h_ret - v);
+              dv = 2.0f * (v - h_ret);
+            }
+            a_vl += vl;
+            dd = dv * bt.vcoef * bt.inv_B;
+          }
+          d[0][t][reg] = dd;
+        }
+      });
+    }
+    // ---- backward
+    sfor<NL>([&](auto LL) {
+      constexpr int l = NL - 1 - LL, cur = LL & 1, nxt = cur ^ 1;
+      constexpr int nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
+      float* xb = (l & 1) ? xb1 : xb0;
+      // park this wave's deltas and layer inputs, transposed, for the workgroup's dW
+      sfor<nto>([&](auto T) {
+        constexpr int t = T;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) xb[(t * kFastWaves + w) * kTileF + (4 * q + reg) * kXT + prow] = d[cur][t][reg];
+      });
+      sfor<nkt>([&](auto T) {
+        constexpr int t = T;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) xb[((nto + t) * kFastWaves + w) * kTileF + (4 * q + reg) * kXT + prow] = a[l][t][reg];
+      });
+      // d_{l-1} = (W' d_l) * ELU'(a_l): registers only
+      if constexpr (l > 0) {
+        const f32x4* __restrict__ wp = net.pb[l] + wlane;
+        sfor<nkt>([&](auto TK) {
+          constexpr int tk = TK;
+          f32x4 acc = {0, 0, 0, 0};
+          sfor<nto>([&](auto TO) {
+            constexpr int to = TO;
+            if constexpr (S::nz(l, to, tk)) {
+              const f32x4 wv = wp[(tk * nto + to) * 64];
+#pragma unroll
+              for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], d[cur][to][j], acc, 0, 0, 0);
+            }
+          });
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) {
+            const int col = 16 * tk + 4 * q + reg;
+            const float av = a[l][tk][reg];
+            d[nxt][tk][reg] = col < S::Kr(l) ? acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f) : 0.0f;   // ELU'(z) from ELU(z); no gradient into the 1-column
+          }
+        });
+      }
+      __syncthreads();
+      // dW_l += D' a_l over the 64 rows of the workgroup: this wave's tiles
+      sfor<S::slots(l)>([&](auto SI) {
+        constexpr int slot = S::slotbase(l) + SI;
+        const int code = net.slot2[w][slot];
+        if (code >= 0) {
+          const float* dp = xb + ((code & 15) * kFastWaves) * kTileF + r * kXT + 4 * q;
+          const float* ap = xb + ((nto + (code >> 4)) * kFastWaves) * kTileF + r * kXT + 4 * q;
+#pragma unroll
+          for (int g = 0; g < kFastWaves; g++) {
+            const f32x4 dv = *reinterpret_cast<const f32x4*>(dp + g * kTileF);
+            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * kTileF);
+#pragma unroll
+            for (int j = 0; j < 4; j++) gw[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[j], av[j], gw[slot], 0, 0, 0);
+          }
+        }
+      });
+    });
+  }
+  // ---- this workgroup's partial gradient
+  float* P = partial + (size_t)blockIdx.x * (net.gtotal + kNS);
+  sfor<NL>([&](auto L) {
+    constexpr int l = L;
+    sfor<S::slots(l)>([&](auto SI) {
+      constexpr int slot = S::slotbase(l) + SI;
+      const int code = net.slot2[w][slot];
+      if (code >= 0) {
+        const int k = 16 * (code >> 4) + r;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) P[net.goff[l] + (16 * (code & 15) + 4 * q + reg) * S::P(l) + k] = gw[slot][reg];
+      }
+    });
+  });
+  for (int o = 1; o < 64; o <<= 1) { a_kl += __shfl_xor(a_kl, o); a_surr += __shfl_xor(a_surr, o); a_vl += __shfl_xor(a_vl, o); }
+  sfor<PO>([&](auto T) {
+    constexpr int t = T;
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      float v = a_dstd[t][reg];
+      v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8);
+      const int f = 16 * t + 4 * q + reg;
+      if (r == 0 && f < 32) hsum[w][f] = v;
+    }
+  });
+  if (lane == 0) { hsum[w][32] = a_kl; hsum[w][33] = a_surr; hsum[w][34] = a_vl; }
+  __syncthreads();
+  if (tid < 35) {
+    float v = 0.0f;
+    for (int g = 0; g < kFastWaves; g++) v += hsum[g][tid];
+    P[net.gtotal + tid] = v;
+  }
+}
+// the reference's networks (envs/nightmare_v3_config.py:107-109): 66 -> 54 -> 42 -> 30 -> 18 | 1
+typedef Shape4<66, 54, 42, 30, 18, 54, 42, 30> RefShape;
+
+// merged [Op x Kp] matrices (bias in column Kr) -> the two MFMA packings of every layer (blockIdx.y = layer).
+//   generic kernel: forward [O tile t][k group g][lane] = Wm[16 t + r][4 (4 g + j) + q], backward [K tile t][o group g][lane] = Wm[4 (4 g + j) + q][16 t + r]
+//   fast kernel   : forward [O tile t][K tile g][lane] = Wm[16 t + r][16 g + 4 q + j],   backward [K tile t][O tile g][lane] = Wm[16 g + 4 q + j][16 t + r]
+__global__ void k_ppo_pack(PpoNet net, const float* __restrict__ Wm_all, int fast) {
+  const int l = blockIdx.y, Op = net.Op[l], Kp = net.Kp[l];
+  const float* __restrict__ Wm = Wm_all + net.goff[l];
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int nf = (Op / 16) * (Kp / 16) * 64;
   if (i >= 2 * nf) return;
   const int which = i / nf, ii = i - which * nf;
   const int lane = ii & 63, r = lane & 15, q = lane >> 4;
   f32x4 v;
-  if (which == 0) {       // forward: [O tile t][k group g][lane]: Wm[16 t + r][4 (4 g + j) + q]
+  if (which == 0) {
     const int ngrp = Kp / 16, g = (ii >> 6) % ngrp, t = (ii >> 6) / ngrp;
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = Wm[(size_t)(16 * t + r) * Kp + 4 * (4 * g + j) + q];
-    pf[ii] = v;
-  } else {                // backward: [K tile t][o group g][lane]: Wm[4 (4 g + j) + q][16 t + r]
+    for (int j = 0; j < 4; j++) v[j] = Wm[(size_t)(16 * t + r) * Kp + (fast ? 16 * g + 4 * q + j : 4 * (4 * g + j) + q)];
+    const_cast<f32x4*>(net.pf[l])[ii] = v;
+  } else {
     const int ngrp = Op / 16, g = (ii >> 6) % ngrp, t = (ii >> 6) / ngrp;
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = Wm[(size_t)(4 * (4 * g + j) + q) * Kp + 16 * t + r];
-    pb[ii] = v;
+    for (int j = 0; j < 4; j++) v[j] = Wm[(size_t)(fast ? 16 * g + 4 * q + j : 4 * (4 * g + j) + q) * Kp + 16 * t + r];
+    const_cast<f32x4*>(net.pb[l])[ii] = v;
   }
 }
 // flat real parameters -> merged matrices (zero elsewhere: the off-diagonal blocks and the padding never change)
@@ -368,6 +656,7 @@ __global__ void k_ppo_adam(float* __restrict__ flat, float* __restrict__ m, floa
 // ------------------------------------------------------------------------------------------------ handle + C ABI
 struct nm_ppo {
   int device = 0, n_layers = 0, A = 0, nparam = 0, nwg = 0, wm_total = 0;
+  bool fast = false;           // the network has the shape k_ppo_fwdbwd_fast is compiled for
   PpoNet net;
   std::vector<int> map_host;
   int* map = nullptr;
@@ -432,6 +721,23 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
           n.slot[w][cnt[w]++] = l | (to << 4) | (tk << 8);
         }
   }
+  // the compiled fast path (NM_PPO_GENERIC=1 keeps such a network on the generic kernel: tests, A/B timing)
+  for (int w = 0; w < kFastWaves; w++) for (int i = 0; i < kFastSlots; i++) n.slot2[w][i] = -1;
+  {
+    typedef RefShape S;
+    bool same = n_layers == S::NL && !(std::getenv("NM_PPO_GENERIC") && std::atoi(std::getenv("NM_PPO_GENERIC")) != 0);
+    for (int l = 0; same && l < S::NL; l++)
+      same = actor_dims[l] == S::ain(l) && critic_dims[l] == S::cin(l) && actor_dims[l + 1] == S::aout(l) && critic_dims[l + 1] == S::cout(l) &&
+             n.Kp[l] == S::P(l) && n.Op[l] == S::P(l + 1);
+    h->fast = same;
+    if (same)
+      for (int l = 0; l < S::NL; l++) {      // the layer's parameter-holding tiles in (o tile, k tile) order, a contiguous run per wave
+        int idx = 0;
+        for (int to = 0; to < S::P(l + 1) / 16; to++)
+          for (int tk = 0; tk < S::P(l) / 16; tk++)
+            if (S::nz(l, to, tk)) { n.slot2[idx / S::slots(l)][S::slotbase(l) + idx % S::slots(l)] = to | (tk << 4); idx++; }
+      }
+  }
   // flat parameter -> merged position
   std::vector<int>& map = h->map_host;
   for (int net_i = 0; net_i < 2; net_i++) {
@@ -470,10 +776,9 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
 extern "C" int32_t nm_ppo_num_params(const nm_ppo* h) { return h ? h->nparam : 0; }
 
 static int ppo_pack(nm_ppo* h, hipStream_t s) {
-  for (int l = 0; l < h->n_layers; l++) {
-    const int Op = h->net.Op[l], Kp = h->net.Kp[l], nthr = 2 * (Op / 16) * (Kp / 16) * 64;
-    hipLaunchKernelGGL(k_ppo_pack, dim3((nthr + 255) / 256), dim3(256), 0, s, h->Wm + h->net.goff[l], h->pf + h->pf_off[l], h->pb + h->pb_off[l], Op, Kp);
-  }
+  int most = 0;
+  for (int l = 0; l < h->n_layers; l++) most = std::max(most, 2 * (h->net.Op[l] / 16) * (h->net.Kp[l] / 16) * 64);
+  hipLaunchKernelGGL(k_ppo_pack, dim3((most + 255) / 256, h->n_layers), dim3(256), 0, s, h->net, h->Wm, h->fast ? 1 : 0);
   return hipGetLastError() == hipSuccess ? 0 : nm_policy_set_error("nm_ppo: pack launch failed");
 }
 // (re)load the parameters from the flat vector (after load_state_dict, or a step taken elsewhere) and set learning rate / step count
@@ -500,9 +805,11 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
   const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + kRedParams - 1) / kRedParams;
   if (phase == 0 || phase == 1) {     // 1: gradient only
     PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value};
-    const int ntiles = (B + kRows - 1) / kRows, grid = ntiles < h->nwg ? ntiles : h->nwg;
+    const int rows = h->fast ? 16 * kFastWaves : kRows;
+    const int ntiles = (B + rows - 1) / rows, grid = ntiles < h->nwg ? ntiles : h->nwg;
     if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
-    hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
+    if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_fast<RefShape>, dim3(grid), dim3(64 * kFastWaves), 0, s, h->net, bt, h->partial);
+    else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
     hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, h->grad);
   }
   if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced nm_ppo_grad()
