@@ -307,12 +307,59 @@ struct Shape4 {
   static constexpr __host__ __device__ int xfloats(int b) { int m = 0; for (int l = b; l < NL; l += 2) { const int n = (P(l) + P(l + 1)) / 16 * kFastWaves * 320; m = n > m ? n : m; } return m; }
 };
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+// -DNM_PPO_STAMPS (measurement builds only): lane 0 of wave 0 adds the s_memtime ticks since its previous stamp to g_ppo_stamps[k]
+#ifdef NM_PPO_STAMPS
+__device__ unsigned long long g_ppo_stamps[16];
+#define PPO_STAMP(k) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long n_ = __builtin_amdgcn_s_memtime(); \
+                          if (tid == 0) atomicAdd(&g_ppo_stamps[k], n_ - t_last); t_last = n_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define PPO_STAMP(k)
+#endif
+
+// Order in which a wave consumes the packed weight fragments (one fragment = the A operand of 4 MFMAs), so that they can stream
+// through a ring of registers `kRing` fragments ahead of their use, across layer boundaries (the compiler left to itself issued
+// load -> wait -> 4 MFMAs, one L2 round trip per fragment):
+//   forward: layer 0..NL-1 | pairs of output tiles (2p, 2p+1) | k tile ascending | even, odd output tile
+//   dX     : layer NL-1..1 | pairs of k tiles (2p, 2p+1)      | o tile ascending | even, odd k tile
+// The two output tiles of a pair are independent accumulation chains that share the B operand: their MFMAs alternate, which also
+// covers the 40-cycle dependent-accumulator latency of v_mfma_f32_16x16x4_f32 (issue 32).
+template <class S> struct Seq {
+  static constexpr int NL = S::NL;
+  // mode 0: number of fragments; mode 1: entry number `arg` as l | to << 4 | tk << 8; mode 2: position of (l, to, tk) packed in arg
+  static constexpr __host__ __device__ int walk(bool fwd, int mode, int arg) {
+    int i = 0;
+    for (int step = 0; step < (fwd ? NL : NL - 1); step++) {
+      const int l = fwd ? step : NL - 1 - step;
+      const int nto = S::P(l + 1) / 16, nkt = S::P(l) / 16;
+      const int nouter = fwd ? nto : nkt, ninner = fwd ? nkt : nto;
+      for (int p = 0; p < (nouter + 1) / 2; p++)
+        for (int in = 0; in < ninner; in++)
+          for (int h = 0; h < 2; h++) {
+            const int o = 2 * p + h;
+            if (o >= nouter) continue;
+            const int to = fwd ? o : in, tk = fwd ? in : o;
+            if (!S::nz(l, to, tk)) continue;
+            const int e = l | (to << 4) | (tk << 8);
+            if (mode == 1 && i == arg) return e;
+            if (mode == 2 && e == arg) return i;
+            i++;
+          }
+    }
+    return mode == 0 ? i : -1;
+  }
+  static constexpr __host__ __device__ int count(bool fwd) { return walk(fwd, 0, 0); }
+  static constexpr __host__ __device__ int entry(bool fwd, int i) { return walk(fwd, 1, i); }
+  static constexpr __host__ __device__ int index(bool fwd, int l, int to, int tk) { return walk(fwd, 2, l | (to << 4) | (tk << 8)); }
+};
+constexpr int kRing = 12;
 
 template <class S>
 __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net, PpoBatch bt, float* __restrict__ partial) {
-  constexpr int NL = S::NL, MT = S::maxT(), PO = S::P(NL) / 16, AO = S::aout(NL - 1), I = S::Kr(0);
+  typedef Seq<S> Q;
+  constexpr int NL = S::NL, MT = S::maxT(), PO = S::P(NL) / 16, AO = S::aout(NL - 1), I = S::Kr(0), T0 = S::P(0) / 16;
+  constexpr int NF = Q::count(true), NB = Q::count(false);
   constexpr int kXT = 20, kTileF = 16 * kXT;       // an exchange tile: 16 features x (16 rows + 4 pad) floats
-  static_assert(S::nslots() <= kFastSlots && AO + 1 <= 32 && PO <= 2, "shape outside the fast kernel's limits");
+  static_assert(S::nslots() <= kFastSlots && AO + 1 <= 32 && PO <= 2 && NF >= kRing && NB >= kRing, "shape outside the fast kernel's limits");
   __shared__ __attribute__((aligned(16))) float xb0[S::xfloats(0)];
   __shared__ __attribute__((aligned(16))) float xb1[S::xfloats(1)];
   __shared__ float hsum[kFastWaves][40];
@@ -328,67 +375,102 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
     for (int reg = 0; reg < 4; reg++) { a_dstd[t][reg] = 0.0f; const int f = 16 * t + 4 * q + reg; sdv[t][reg] = f < AO ? bt.std[f] : 1.0f; }
   });
   const int npass = (bt.B + 16 * kFastWaves - 1) / (16 * kFastWaves);
-  for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+#ifdef NM_PPO_STAMPS
+  unsigned long long t_last = __builtin_amdgcn_s_memtime();
+#endif
+  // per-row data of a pass: the observation tile (B operand of layer 0) and what the loss head needs. Loaded one pass ahead - these
+  // come from HBM, and vmcnt retires in order: a wait for the first weight fragment would otherwise sit behind their full latency.
+  struct RowData { f32x4 obs[T0], act[PO], omu[PO], osd[PO]; float adv, olp, ret, tv; };
+  auto load_rows = [&](int pass, RowData& rd) {
     const int row = (pass * kFastWaves + w) * 16 + r;
-    const bool live = row < bt.B;
-    int wlane = lane;          // opaque per pass: the 135 weight fragments are re-read from L2 every pass, not hoisted out of the loop into 540 registers
-    asm volatile("" : "+v"(wlane));
-    const size_t lrow = live ? row : 0;
-    f32x4 a[NL][MT], d[2][MT], out[PO];
-    // ---- observation tile (B operand of layer 0) and the head's per-row data (used much later: their latency hides behind the forward)
-    sfor<S::P(0) / 16>([&](auto T) {
+    const size_t lrow = row < bt.B ? row : 0;
+    sfor<T0>([&](auto T) {
       constexpr int t = T;
-      f32x4 v = {0, 0, 0, 0};
       if constexpr (16 * t + 16 <= I) {
-        v = *reinterpret_cast<const f32x4u*>(bt.obs + lrow * I + 16 * t + 4 * q);
+        rd.obs[t] = *reinterpret_cast<const f32x4u*>(bt.obs + lrow * I + 16 * t + 4 * q);
       } else {
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) { const int f = 16 * t + 4 * q + reg; v[reg] = f < I ? bt.obs[lrow * I + f] : (f == I ? 1.0f : 0.0f); }
+        for (int reg = 0; reg < 4; reg++) { const int f = 16 * t + 4 * q + reg; const float v = bt.obs[lrow * I + (f < I ? f : 0)]; rd.obs[t][reg] = f < I ? v : (f == I ? 1.0f : 0.0f); }
       }
-      if (!live) v = f32x4{0, 0, 0, 0};
-      a[0][t] = v;
     });
-    f32x4 h_act[PO], h_omu[PO], h_osd[PO];
     sfor<PO>([&](auto T) {
       constexpr int t = T;
 #pragma unroll
       for (int reg = 0; reg < 4; reg++) {
         const int f = 16 * t + 4 * q + reg;
-        const bool on = f < AO;
-        h_act[t][reg] = on ? bt.actions[lrow * AO + f] : 0.0f;
-        h_omu[t][reg] = on ? bt.old_mu[lrow * AO + f] : 0.0f;
-        h_osd[t][reg] = on ? bt.old_sigma[lrow * AO + f] : 1.0f;
+        const size_t at = lrow * AO + (f < AO ? f : 0);
+        rd.act[t][reg] = bt.actions[at]; rd.omu[t][reg] = bt.old_mu[at]; rd.osd[t][reg] = bt.old_sigma[at];
       }
     });
-    const float h_adv = bt.adv[lrow], h_olp = bt.old_logp[lrow], h_ret = bt.ret[lrow], h_tv = bt.tval[lrow];
+    rd.adv = bt.adv[lrow]; rd.olp = bt.old_logp[lrow]; rd.ret = bt.ret[lrow]; rd.tv = bt.tval[lrow];
+  };
+  RowData nx;
+  f32x4 ring[kRing];
+  int wlane = lane;            // made opaque once per pass: the 135 weight fragments are re-read from L2 every pass, not hoisted out of the loop into 540 registers
+  asm volatile("" : "+v"(wlane));
+  auto wfrag = [&](auto FWD, auto IDX) -> f32x4 {
+    constexpr bool fwd = FWD;
+    constexpr int e = Q::entry(fwd, IDX), l = e & 15, to = (e >> 4) & 15, tk = e >> 8;
+    if constexpr (fwd) return net.pf[l][(to * (S::P(l) / 16) + tk) * 64 + wlane];
+    else return net.pb[l][(tk * (S::P(l + 1) / 16) + to) * 64 + wlane];
+  };
+  if (blockIdx.x < npass) load_rows(blockIdx.x, nx);
+  sfor<kRing>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); });
+  for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+    PPO_STAMP(15);
+    const int row = (pass * kFastWaves + w) * 16 + r;
+    const bool live = row < bt.B;
+    const RowData cu = nx;
+    f32x4 a[NL][MT], d[2][MT], out[PO];
+    sfor<T0>([&](auto T) { a[0][T] = live ? cu.obs[T] : f32x4{0, 0, 0, 0}; });
+    PPO_STAMP(0);
     // ---- forward
     sfor<NL>([&](auto L) {
       constexpr int l = L, nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
       constexpr bool last = l == NL - 1;
-      const f32x4* __restrict__ wp = net.pf[l] + wlane;
-      sfor<nto>([&](auto TO) {
-        constexpr int to = TO;
-        f32x4 acc = {0, 0, 0, 0};
+      if constexpr (l > 0) PPO_STAMP(l);
+      sfor<(nto + 1) / 2>([&](auto PP) {
+        constexpr int to0 = 2 * PP, to1 = to0 + 1;
+        f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         sfor<nkt>([&](auto TK) {
           constexpr int tk = TK;
-          if constexpr (S::nz(l, to, tk)) {
-            const f32x4 wv = wp[(to * nkt + tk) * 64];
+          constexpr bool z0 = S::nz(l, to0, tk), z1 = to1 < nto && S::nz(l, to1, tk);
+          f32x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+          if constexpr (z0) {
+            constexpr int i = Q::index(true, l, to0, tk);
+            w0 = ring[i % kRing];
+            if constexpr (i + kRing < NF) ring[i % kRing] = wfrag(std::true_type{}, std::integral_constant<int, (i + kRing < NF ? i + kRing : 0)>{});
+          }
+          if constexpr (z1) {
+            constexpr int i = Q::index(true, l, to1, tk);
+            w1 = ring[i % kRing];
+            if constexpr (i + kRing < NF) ring[i % kRing] = wfrag(std::true_type{}, std::integral_constant<int, (i + kRing < NF ? i + kRing : 0)>{});
+          }
 #pragma unroll
-            for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], a[l][tk][j], acc, 0, 0, 0);
+          for (int j = 0; j < 4; j++) {
+            if constexpr (z0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[l][tk][j], acc0, 0, 0, 0);
+            if constexpr (z1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[l][tk][j], acc1, 0, 0, 0);
           }
         });
-        if constexpr (last) {
-          out[to] = acc;
-        } else {
+        auto finish = [&](auto TO, const f32x4& acc) {
+          constexpr int to = TO;
+          if constexpr (last) {
+            out[to] = acc;
+          } else {
 #pragma unroll
-          for (int reg = 0; reg < 4; reg++) {
-            const int col = 16 * to + 4 * q + reg;
-            const float v = acc[reg];
-            a[l + 1][to][reg] = col < S::Or(l) ? (v > 0.0f ? v : __expf(v) - 1.0f) : (col == S::Or(l) ? 1.0f : 0.0f);   // ELU | bias carrier | padding
+            for (int reg = 0; reg < 4; reg++) {
+              const int col = 16 * to + 4 * q + reg;
+              const float v = acc[reg];
+              a[l + 1][to][reg] = col < S::Or(l) ? (v > 0.0f ? v : __expf(v) - 1.0f) : (col == S::Or(l) ? 1.0f : 0.0f);   // ELU | bias carrier | padding
+            }
           }
-        }
+        };
+        finish(std::integral_constant<int, to0>{}, acc0);
+        if constexpr (to1 < nto) finish(std::integral_constant<int, to1>{}, acc1);
       });
     });
+    PPO_STAMP(4);
+    sfor<kRing>([&](auto i) { ring[i] = wfrag(std::false_type{}, i); });      // the dX fragments start to arrive behind the loss head
     // ---- loss head: lane (row r, q) holds outputs 16 t + 4 q + reg; per-row sums cross the four q lanes
     {
       float lp = 0.0f, kl = 0.0f;
@@ -398,8 +480,8 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
         for (int reg = 0; reg < 4; reg++) {
           const int f = 16 * t + 4 * q + reg;
           if (f < AO) {
-            const float mu = out[t][reg], sd = sdv[t][reg], osd = h_osd[t][reg], omu = h_omu[t][reg];
-            const float z = (h_act[t][reg] - mu) / sd;
+            const float mu = out[t][reg], sd = sdv[t][reg], osd = cu.osd[t][reg], omu = cu.omu[t][reg];
+            const float z = (cu.act[t][reg] - mu) / sd;
             lp += -0.5f * z * z - __logf(sd) - 0.9189385332046727f;
             kl += __logf(sd / osd + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) / (2.0f * sd * sd) - 0.5f;
           }
@@ -408,12 +490,12 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
       lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
       float dlogp = 0.0f;      // d(surrogate)/d(logp) * (1/B)
       if (live) {
-        const float ratio = __expf(lp - h_olp);
-        const float s1 = -h_adv * ratio, rc = fminf(fmaxf(ratio, 1.0f - bt.clip), 1.0f + bt.clip), s2 = -h_adv * rc;
+        const float ratio = __expf(lp - cu.olp);
+        const float s1 = -cu.adv * ratio, rc = fminf(fmaxf(ratio, 1.0f - bt.clip), 1.0f + bt.clip), s2 = -cu.adv * rc;
         const bool inside = ratio > 1.0f - bt.clip && ratio < 1.0f + bt.clip;
         // torch.max(s1, s2).backward(): the larger branch gets the gradient, a tie splits it; the clipped branch has zero slope outside the range
         const float g1 = s1 > s2 ? 1.0f : (s1 == s2 ? 0.5f : 0.0f), g2 = 1.0f - g1;
-        dlogp = (g1 * (-h_adv * ratio) + g2 * (inside ? -h_adv * ratio : 0.0f)) * bt.inv_B;
+        dlogp = (g1 * (-cu.adv * ratio) + g2 * (inside ? -cu.adv * ratio : 0.0f)) * bt.inv_B;
         a_kl += kl;
         if (q == 0) a_surr += fmaxf(s1, s2);
       }
@@ -424,22 +506,22 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
           const int f = 16 * t + 4 * q + reg;
           float dd = 0.0f;
           if (live && f < AO) {
-            const float mu = out[t][reg], sd = sdv[t][reg], am = h_act[t][reg] - mu;
+            const float mu = out[t][reg], sd = sdv[t][reg], am = cu.act[t][reg] - mu;
             dd = dlogp * am / (sd * sd);
             a_dstd[t][reg] += dlogp * (am * am / (sd * sd * sd) - 1.0f / sd);
           } else if (live && f == AO) {
             const float v = out[t][reg];
             float dv, vl;
             if (bt.clip_value) {
-              const float dvt = v - h_tv, vc = h_tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
-              const float l1 = (v - h_ret) * (v - h_ret), l2 = (vc - h_ret) * (vc - h_ret);
+              const float dvt = v - cu.tv, vc = cu.tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
+              const float l1 = (v - cu.ret) * (v - cu.ret), l2 = (vc - cu.ret) * (vc - cu.ret);
               const bool in2 = dvt > -bt.clip && dvt < bt.clip;
               const float h1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), h2 = 1.0f - h1;
               vl = fmaxf(l1, l2);
-              dv = h1 * 2.0f * (v - h_ret) + h2 * (in2 ? 2.0f * (vc - h_ret) : 0.0f);
+              dv = h1 * 2.0f * (v - cu.ret) + h2 * (in2 ? 2.0f * (vc - cu.ret) : 0.0f);
             } else {
-              vl = (h_ret - v) * (h_ret - v);
-              dv = 2.0f * (v - h_ret);
+              vl = (cu.ret - v) * (cu.ret - v);
+              dv = 2.0f * (v - cu.ret);
             }
             a_vl += vl;
             dd = dv * bt.vcoef * bt.inv_B;
@@ -448,11 +530,13 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
         }
       });
     }
+    PPO_STAMP(5);
     // ---- backward
     sfor<NL>([&](auto LL) {
       constexpr int l = NL - 1 - LL, cur = LL & 1, nxt = cur ^ 1;
       constexpr int nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
       float* xb = (l & 1) ? xb1 : xb0;
+      if constexpr (LL > 0) PPO_STAMP(5 + 2 * LL);
       // park this wave's deltas and layer inputs, transposed, for the workgroup's dW
       sfor<nto>([&](auto T) {
         constexpr int t = T;
@@ -466,45 +550,79 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
       });
       // d_{l-1} = (W' d_l) * ELU'(a_l): registers only
       if constexpr (l > 0) {
-        const f32x4* __restrict__ wp = net.pb[l] + wlane;
-        sfor<nkt>([&](auto TK) {
-          constexpr int tk = TK;
-          f32x4 acc = {0, 0, 0, 0};
+        sfor<(nkt + 1) / 2>([&](auto PP) {
+          constexpr int tk0 = 2 * PP, tk1 = tk0 + 1;
+          f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
           sfor<nto>([&](auto TO) {
             constexpr int to = TO;
-            if constexpr (S::nz(l, to, tk)) {
-              const f32x4 wv = wp[(tk * nto + to) * 64];
+            constexpr bool z0 = S::nz(l, to, tk0), z1 = tk1 < nkt && S::nz(l, to, tk1);
+            f32x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+            if constexpr (z0) {
+              constexpr int i = Q::index(false, l, to, tk0);
+              w0 = ring[i % kRing];
+              if constexpr (i + kRing < NB) ring[i % kRing] = wfrag(std::false_type{}, std::integral_constant<int, (i + kRing < NB ? i + kRing : 0)>{});
+            }
+            if constexpr (z1) {
+              constexpr int i = Q::index(false, l, to, tk1);
+              w1 = ring[i % kRing];
+              if constexpr (i + kRing < NB) ring[i % kRing] = wfrag(std::false_type{}, std::integral_constant<int, (i + kRing < NB ? i + kRing : 0)>{});
+            }
 #pragma unroll
-              for (int j = 0; j < 4; j++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[j], d[cur][to][j], acc, 0, 0, 0);
+            for (int j = 0; j < 4; j++) {
+              if constexpr (z0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], d[cur][to][j], acc0, 0, 0, 0);
+              if constexpr (z1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], d[cur][to][j], acc1, 0, 0, 0);
             }
           });
+          auto finish = [&](auto TK, const f32x4& acc) {
+            constexpr int tk = TK;
 #pragma unroll
-          for (int reg = 0; reg < 4; reg++) {
-            const int col = 16 * tk + 4 * q + reg;
-            const float av = a[l][tk][reg];
-            d[nxt][tk][reg] = col < S::Kr(l) ? acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f) : 0.0f;   // ELU'(z) from ELU(z); no gradient into the 1-column
-          }
+            for (int reg = 0; reg < 4; reg++) {
+              const int col = 16 * tk + 4 * q + reg;
+              const float av = a[l][tk][reg];
+              d[nxt][tk][reg] = col < S::Kr(l) ? acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f) : 0.0f;   // ELU'(z) from ELU(z); no gradient into the 1-column
+            }
+          };
+          finish(std::integral_constant<int, tk0>{}, acc0);
+          if constexpr (tk1 < nkt) finish(std::integral_constant<int, tk1>{}, acc1);
         });
       }
+      if constexpr (l == 1) {
+        // the last weight fragment of this pass has been consumed; what follows (dW of layers 1 and 0) waits on LDS only. Fetch the next
+        // pass's rows (HBM) and the first forward fragments now: they retire in order long before the next pass waits on vmcnt
+        asm volatile("" : "+v"(wlane));
+        if (pass + (int)gridDim.x < npass) load_rows(pass + gridDim.x, nx);
+        sfor<kRing>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); });
+      }
+      PPO_STAMP(6 + 2 * LL);
       __syncthreads();
-      // dW_l += D' a_l over the 64 rows of the workgroup: this wave's tiles
-      sfor<S::slots(l)>([&](auto SI) {
-        constexpr int slot = S::slotbase(l) + SI;
-        const int code = net.slot2[w][slot];
-        if (code >= 0) {
-          const float* dp = xb + ((code & 15) * kFastWaves) * kTileF + r * kXT + 4 * q;
-          const float* ap = xb + ((nto + (code >> 4)) * kFastWaves) * kTileF + r * kXT + 4 * q;
+      // dW_l += D' a_l over the 64 rows of the workgroup: this wave's tiles. An unused slot of the table computes on tile (0, 0) into
+      // an accumulator that is never stored - no branch; the operands of slot i + 1 are read from LDS while slot i multiplies.
+      {
+        constexpr int NS = S::slots(l), SB = S::slotbase(l);
+        f32x4 fd[2][kFastWaves], fa[2][kFastWaves];
+        auto frags = [&](auto SI, auto BUF) {
+          const int code = net.slot2[w][SB + SI], c = code < 0 ? 0 : code;
+          const float* dp = xb + ((c & 15) * kFastWaves) * kTileF + r * kXT + 4 * q;
+          const float* ap = xb + ((nto + (c >> 4)) * kFastWaves) * kTileF + r * kXT + 4 * q;
 #pragma unroll
           for (int g = 0; g < kFastWaves; g++) {
-            const f32x4 dv = *reinterpret_cast<const f32x4*>(dp + g * kTileF);
-            const f32x4 av = *reinterpret_cast<const f32x4*>(ap + g * kTileF);
-#pragma unroll
-            for (int j = 0; j < 4; j++) gw[slot] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[j], av[j], gw[slot], 0, 0, 0);
+            fd[BUF][g] = *reinterpret_cast<const f32x4*>(dp + g * kTileF);
+            fa[BUF][g] = *reinterpret_cast<const f32x4*>(ap + g * kTileF);
           }
-        }
-      });
+        };
+        frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        sfor<NS>([&](auto SI) {
+          constexpr int si = SI, buf = si & 1;
+          if constexpr (si + 1 < NS) frags(std::integral_constant<int, (si + 1 < NS ? si + 1 : 0)>{}, std::integral_constant<int, buf ^ 1>{});
+#pragma unroll
+          for (int g = 0; g < kFastWaves; g++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) gw[SB + si] = __builtin_amdgcn_mfma_f32_16x16x4f32(fd[buf][g][j], fa[buf][g][j], gw[SB + si], 0, 0, 0);
+        });
+      }
     });
   }
+  PPO_STAMP(13);
   // ---- this workgroup's partial gradient
   float* P = partial + (size_t)blockIdx.x * (net.gtotal + kNS);
   sfor<NL>([&](auto L) {
@@ -537,6 +655,7 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
     for (int g = 0; g < kFastWaves; g++) v += hsum[g][tid];
     P[net.gtotal + tid] = v;
   }
+  PPO_STAMP(14);
 }
 // the reference's networks (envs/nightmare_v3_config.py:107-109): 66 -> 54 -> 42 -> 30 -> 18 | 1
 typedef Shape4<66, 54, 42, 30, 18, 54, 42, 30> RefShape;
@@ -666,6 +785,13 @@ struct nm_ppo {
   std::vector<size_t> pf_off, pb_off;
 };
 
+#ifdef NM_PPO_STAMPS
+extern "C" int nm_ppo_read_stamps(unsigned long long* out16, int clear) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_ppo_stamps), 16 * sizeof(unsigned long long)) != hipSuccess) return 1;
+  if (clear) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_ppo_stamps), z, sizeof z) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
 #define PPO_CHK(x) do { if ((x) != hipSuccess) return nm_policy_set_error("nm_ppo: " #x " failed"); } while (0)
 
 extern "C" int nm_ppo_destroy(nm_ppo* h) {
