@@ -148,12 +148,14 @@ int nm_gae(const float* rewards_dev, const float* values_dev, const unsigned cha
  *   draws a = mean + std * N(0,1) from the counter generator keyed by (seed, *iter_dev, step, env, j) and writes step `step` of the rollout
  *   storage: actions/mu/sigma [N,A], log-probability and value [N], and (if obs_store_dev != NULL) a copy of obs_dev [N, n_obs].
  * nm_ppo_record: rewards_store = rew + gamma * value * time_out (time_outs_dev may be NULL), dones_store (u8), running episode return /
- *   length per env, and fin3_dev += (sum of returns, sum of lengths, count) over the episodes that ended in this step. */
+ *   length per env, and fin3_dev += (sum of returns, sum of lengths, count) over the episodes that ended in this step; if n_ep > 0 also the
+ *   runner's sum of extras['episode'] over the rollout: ep_acc_dev[i] += ep_stats_dev[ep_idx_dev[i]], i < n_ep <= 256. */
 int nm_ppo_sample(const float* net_out_dev, const float* std_dev, const float* obs_dev, int32_t N, int32_t A, int32_t n_obs, uint64_t seed,
                   const int64_t* iter_dev, int32_t step, float* actions_dev, float* logp_dev, float* values_dev, float* mu_dev, float* sigma_dev,
                   float* obs_store_dev, void* stream);
 int nm_ppo_record(const float* rew_dev, const int64_t* done_dev, const float* time_outs_dev, const float* values_dev, float gamma, int32_t N,
-                  float* rewards_store_dev, unsigned char* dones_store_dev, float* cur_ret_dev, float* cur_len_dev, float* fin3_dev, void* stream);
+                  float* rewards_store_dev, unsigned char* dones_store_dev, float* cur_ret_dev, float* cur_len_dev, float* fin3_dev,
+                  const float* ep_stats_dev, const int32_t* ep_idx_dev, int32_t n_ep, float* ep_acc_dev, void* stream);
 
 /* ---- PPO mini-batch update (rsl_rl v1.0.2 `algorithms/ppo.py` PPO.update: clipped surrogate + clipped value loss + entropy bonus,
  * adaptive-KL learning rate, gradient-norm clipping, Adam; caller reference train.py:54; hyper-parameters envs/nightmare_v3_config.py:111-128)

@@ -67,7 +67,7 @@ def load():
     L.nm_set_ablation.argtypes = [vp, C.c_int32]
     L.nm_gae.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp]
     L.nm_ppo_sample.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
-    L.nm_ppo_record.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int32, vp, vp, vp, vp, vp, vp]
+    L.nm_ppo_record.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp]
     L.nm_ppo_create.argtypes = [vp, vp, C.c_int32, C.c_int32, C.POINTER(vp)]
     L.nm_ppo_destroy.argtypes = [vp]
     L.nm_ppo_num_params.argtypes = [vp]

@@ -91,8 +91,10 @@ extern "C" int nm_ppo_sample(const float* net_out, const float* std, const float
 // (rewards += gamma * value * time_out), done flag, running episode return / length, and the sums over episodes that ended.
 __global__ void k_ppo_record(const float* __restrict__ rew, const int64_t* __restrict__ done, const float* __restrict__ time_outs,
                              const float* __restrict__ values, float gamma, int N, float* __restrict__ rewards_store, unsigned char* __restrict__ dones_store,
-                             float* __restrict__ cur_ret, float* __restrict__ cur_len, float* __restrict__ fin3) {
+                             float* __restrict__ cur_ret, float* __restrict__ cur_len, float* __restrict__ fin3,
+                             const float* __restrict__ ep_stats, const int* __restrict__ ep_idx, int n_ep, float* __restrict__ ep_acc) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n_ep) ep_acc[e] += ep_stats[ep_idx[e]];      // the runner's running sum of extras['episode'] over the rollout (n_ep <= 256: block 0)
   if (e >= N) return;
   const float r = rew[e];
   const bool d = done[e] > 0;
@@ -104,10 +106,12 @@ __global__ void k_ppo_record(const float* __restrict__ rew, const int64_t* __res
   cur_len[e] = d ? 0.0f : cl;
 }
 extern "C" int nm_ppo_record(const float* rew, const int64_t* done, const float* time_outs, const float* values, float gamma, int32_t N,
-                             float* rewards_store, unsigned char* dones_store, float* cur_ret, float* cur_len, float* fin3, void* stream) {
+                             float* rewards_store, unsigned char* dones_store, float* cur_ret, float* cur_len, float* fin3,
+                             const float* ep_stats, const int32_t* ep_idx, int32_t n_ep, float* ep_acc, void* stream) {
   if (!rew || !done || !values || !rewards_store || !dones_store || !cur_ret || !cur_len || !fin3 || N <= 0) return nm_policy_set_error("nm_ppo_record: bad argument");
+  if (n_ep < 0 || n_ep > 256 || (n_ep > 0 && (!ep_stats || !ep_idx || !ep_acc))) return nm_policy_set_error("nm_ppo_record: bad episode-statistics arguments");
   hipLaunchKernelGGL(k_ppo_record, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, rew, done, time_outs, values, gamma, N, rewards_store,
-                     dones_store, cur_ret, cur_len, fin3);
+                     dones_store, cur_ret, cur_len, fin3, ep_stats, ep_idx, n_ep, ep_acc);
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_record: launch failed");
   return 0;
 }

@@ -64,12 +64,14 @@ class FusedCollector:
                                          storage.observations[s].data_ptr(), stream))
         return storage.actions[s]
 
-    def record(self, storage, rewards, dones, time_outs, gamma, cur_ret, cur_len, fin):
+    def record(self, storage, rewards, dones, time_outs, gamma, cur_ret, cur_len, fin, ep=None):
+        """ep = (ep_stats [K] f32, ep_idx [n] int32, ep_acc [n] f32) device tensors: ep_acc += ep_stats[ep_idx] in the same launch."""
         s = storage.step
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        eps, epi, n_ep, epa = (ep[0].data_ptr(), ep[1].data_ptr(), int(ep[1].numel()), ep[2].data_ptr()) if ep is not None else (None, None, 0, None)
         _lib.check(self._L.nm_ppo_record(rewards.data_ptr(), dones.data_ptr(), None if time_outs is None else time_outs.data_ptr(),
                                          storage.values[s].data_ptr(), float(gamma), self.N, storage.rewards[s].data_ptr(),
-                                         storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(), stream))
+                                         storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(), eps, epi, n_ep, epa, stream))
         storage.step += 1
 
 

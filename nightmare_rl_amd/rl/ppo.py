@@ -70,16 +70,17 @@ class PPO:
         t.critic_observations = t.observations if critic_obs is obs else critic_obs.clone()
         return t.actions
 
-    def process_env_step(self, rewards, dones, infos, stats=None):
+    def process_env_step(self, rewards, dones, infos, stats=None, ep=None):
         """stats = (cur_ret, cur_len, fin) device tensors of the runner's episode bookkeeping: with the fused collector they are
-        updated in the same launch; returns True then (the caller skips its own bookkeeping)."""
+        updated in the same launch; returns True then (the caller skips its own bookkeeping). ep = (ep_stats, ep_idx int32, ep_acc):
+        the running sum of extras['episode'], also in that launch."""
         if getattr(self, "fused", None) is not None and self.transition.actions is None:
             if stats is None:   # a caller without episode bookkeeping of its own
                 if getattr(self, "_own_stats", None) is None:
                     n = rewards.shape[0]
                     self._own_stats = (torch.zeros(n, device=self.device), torch.zeros(n, device=self.device), torch.zeros(3, device=self.device))
                 stats = self._own_stats
-            self.fused.record(self.storage, rewards, dones, infos.get("time_outs"), self.gamma, *stats)
+            self.fused.record(self.storage, rewards, dones, infos.get("time_outs"), self.gamma, *stats, ep=ep)
             return True
         t = self.transition
         t.rewards = rewards.clone()

@@ -82,25 +82,34 @@ class OnPolicyRunner:
                 o, priv_, rewards, dones, infos = env.step(actions)
                 o, rewards, dones = o.to(dev), rewards.to(dev), dones.to(dev)
                 co = priv_.to(dev) if priv_ is not None else o
-                if not alg.process_env_step(rewards, dones, infos, stats=(cur_ret, cur_len, fin)):
+                ep = None
+                if "episode" in infos and hasattr(env, "_ep_stats") and hasattr(env, "_stat_names"):
+                    keys = sorted(infos["episode"])
+                    if state.get("ep_idx") is None:
+                        state["ep_idx"] = torch.tensor([env._stat_names.index(k[4:]) for k in keys], device=dev, dtype=torch.int32)
+                        state["ep_idx64"] = state["ep_idx"].long()
+                    if ep_acc is None:
+                        ep_acc = torch.zeros(len(keys), device=dev)
+                    state["ep_keys"] = keys
+                    ep = (env._ep_stats, state["ep_idx"], ep_acc)
+                fused = alg.process_env_step(rewards, dones, infos, stats=(cur_ret, cur_len, fin), ep=ep)
+                if not fused:
                     cur_ret.add_(rewards)
                     cur_len.add_(1)
                     d = (dones > 0).float()
                     fin.add_(torch.stack([(cur_ret * d).sum(), (cur_len * d).sum(), d.sum()]))
                     cur_ret.mul_(1 - d)
                     cur_len.mul_(1 - d)
-                if "episode" in infos:
-                    keys = sorted(infos["episode"])
-                    if hasattr(env, "_ep_stats") and hasattr(env, "_stat_names"):   # one gather from the env's statistics buffer
-                        if state.get("ep_idx") is None:
-                            state["ep_idx"] = torch.tensor([env._stat_names.index(k[4:]) for k in keys], device=dev)
-                        e = env._ep_stats.index_select(0, state["ep_idx"])
+                if "episode" in infos and not (fused and ep is not None):    # the fused record launch has added it already
+                    if ep is not None:
+                        e = env._ep_stats.index_select(0, state["ep_idx64"])
                     else:
+                        keys = sorted(infos["episode"])
                         e = torch.stack([infos["episode"][k].float() for k in keys])
+                        state["ep_keys"] = keys
                     if ep_acc is None:
                         ep_acc = torch.zeros_like(e)
                     ep_acc.add_(e)
-                    state["ep_keys"] = keys
             state["obs"], state["critic_obs"] = o, co
 
         want_graph = bool(self.cfg.get("graph_rollout", True)) and torch.device(dev).type == "cuda" and hasattr(env, "_h") \
