@@ -169,13 +169,16 @@ int32_t nm_ppo_num_params(const nm_ppo* h);
 /* (re)read the flat parameters (after load_state_dict or a step taken elsewhere) and set the learning rate / Adam step count */
 int nm_ppo_sync_params(nm_ppo* h, const float* flat_dev, float lr, int64_t step, void* stream);
 /* one mini-batch: rows of obs [B,n_obs], actions / old_mu / old_sigma [B,A], old_logp / adv / ret / target_values [B] (device f32).
- * phase 0 = everything; 1 = gradient only (fetch it with nm_ppo_copy_grad, e.g. for an all-reduce); 2 = the step from the current gradient
- * (kl_override >= 0 replaces the local KL mean in the learning-rate rule, < 0 keeps it). */
+ * phase 0 = everything; 1 = gradient only (fetch it with nm_ppo_copy_grad, e.g. for an all-reduce); 2 = the step from the current gradient, the KL of the
+ * learning-rate rule read from the slot behind it (kl_override >= 0 replaces the KL mean in either phase, < 0 keeps it).
+ * Data-parallel update: phase 1, nm_ppo_copy_grad(0), all-reduce + divide by the ranks, nm_ppo_copy_grad(1), phase 2 - one collective
+ * per mini-batch, no host synchronisation. */
 int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
                      const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* target_values,
                      int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
                      int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
-/* gradient of the last mini-batch, flat order [num_params]: direction 0 copies it to grad_dev, 1 replaces it by grad_dev */
+/* gradient of the last mini-batch in flat order followed by the mini-batch's mean KL to the behaviour policy, [num_params + 1] floats:
+ * direction 0 copies them to grad_dev, 1 replaces them by grad_dev */
 int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream);
 /* HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, grad norm;
  * reset_sums != 0 clears the two loss sums and the count afterwards. Synchronises the stream. */

@@ -693,16 +693,17 @@ __global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restr
 // plus the entropy bonus -c_e * d(sum_j log std_j)/d(std_j))
 constexpr int kRedParams = 64, kRedWaves = 8;
 __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
-                             const float* __restrict__ flat, float ent_coef, float* __restrict__ grad) {
-  // a block sums 64 consecutive parameters: wave w takes workgroups w, w + 8, ... (independent loads, 256 B runs), LDS joins the waves
+                             const float* __restrict__ flat, float ent_coef, float inv_B, float* __restrict__ grad) {
+  // entry n (one past the parameters) = this mini-batch's mean KL to the behaviour policy: it travels with the gradient through a
+  // multi-GPU all-reduce. A block sums 64 consecutive parameters: wave w takes workgroups w, w + 8, ... (independent loads, 256 B runs), LDS joins the waves
   // in a fixed order - the result does not depend on scheduling
   __shared__ float part[kRedWaves][kRedParams];
   const int lane = threadIdx.x & 63, w0 = threadIdx.x >> 6;
   const int i = blockIdx.x * kRedParams + lane;
   float g = 0.0f;
   int m = 0;
-  if (i < n) {
-    m = map[i];
+  if (i <= n) {
+    m = i < n ? map[i] : -33;
     const float* P = partial + (m >= 0 ? m : gtotal + (-m - 1));
     float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
     int w = w0;
@@ -715,17 +716,18 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const flo
   }
   part[w0][lane] = g;
   __syncthreads();
-  if (w0 == 0 && i < n) {
+  if (w0 == 0 && i <= n) {
     g = 0.0f;
 #pragma unroll
     for (int w = 0; w < kRedWaves; w++) g += part[w][lane];
-    if (m < 0) g -= ent_coef / flat[i];
+    if (i == n) g *= inv_B;
+    else if (m < 0) g -= ent_coef / flat[i];
     grad[i] = g;
   }
 }
 // state: [0] lr [1] step [2] last kl [3] sum of value losses [4] sum of surrogate losses [5] mini-batches [6] clip coefficient [7] grad norm
 __global__ void k_ppo_scalars(const float* __restrict__ partial, int nwg, int stride, int gtotal, const float* __restrict__ grad, int n, float inv_B,
-                              float desired_kl, int adaptive, float max_norm, float kl_override, float* __restrict__ state) {
+                              float desired_kl, int adaptive, float max_norm, float kl_override, int kl_from_grad, float* __restrict__ state) {
   __shared__ float red[4][32];
   const int tid = threadIdx.x;
   float kl = 0, su = 0, vl = 0, n2 = 0;
@@ -741,7 +743,8 @@ __global__ void k_ppo_scalars(const float* __restrict__ partial, int nwg, int st
     kl = su = vl = n2 = 0;
     for (int w = 0; w < (int)(blockDim.x >> 6); w++) { kl += red[0][w]; su += red[1][w]; vl += red[2][w]; n2 += red[3][w]; }
     float klm = kl * inv_B;
-    if (kl_override >= 0.0f) klm = kl_override;       // multi-GPU: the caller all-reduced the KL and passes the global mean
+    if (kl_from_grad) klm = grad[n];                   // multi-GPU: the caller all-reduced gradient | KL (nm_ppo_copy_grad) and divided by the ranks
+    if (kl_override >= 0.0f) klm = kl_override;
     float lr = state[0];
     if (adaptive) {                                    // rsl_rl v1.0.2 PPO.update: schedule == 'adaptive'
       if (klm > desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
@@ -889,7 +892,7 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
   bool ok = hipMalloc((void**)&h->map, map.size() * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->Wm, (size_t)h->wm_total * sizeof(float)) == hipSuccess &&
             hipMalloc((void**)&h->pf, pft * sizeof(f32x4)) == hipSuccess && hipMalloc((void**)&h->pb, pbt * sizeof(f32x4)) == hipSuccess &&
             hipMalloc((void**)&h->partial, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)) == hipSuccess &&
-            hipMalloc((void**)&h->grad, map.size() * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->state, 8 * sizeof(float)) == hipSuccess;
+            hipMalloc((void**)&h->grad, (map.size() + 1) * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->state, 8 * sizeof(float)) == hipSuccess;
   if (!ok) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: hipMalloc failed"); }
   PPO_CHK(hipMemcpy(h->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
   PPO_CHK(hipMemset(h->Wm, 0, (size_t)h->wm_total * sizeof(float)));
@@ -928,7 +931,7 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
   if (n_obs != h->net.Kr[0]) return nm_policy_set_error("nm_ppo_minibatch: observation width does not match the network");
   PPO_CHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + kRedParams - 1) / kRedParams;
+  const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + 1 + kRedParams - 1) / kRedParams;
   if (phase == 0 || phase == 1) {     // 1: gradient only
     PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value};
     const int rows = h->fast ? 16 * kFastWaves : kRows;
@@ -936,22 +939,23 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
     if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
     if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_fast<RefShape>, dim3(grid), dim3(64 * kFastWaves), 0, s, h->net, bt, h->partial);
     else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
-    hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, h->grad);
+    hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
   }
-  if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced nm_ppo_grad()
+  if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced gradient | KL; the KL is then read from there
     hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nwg, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,
-                       adaptive, max_grad_norm, kl_override, h->state);
+                       adaptive, max_grad_norm, kl_override, phase == 2 ? 1 : 0, h->state);
     hipLaunchKernelGGL(k_ppo_adam, dim3(nb), dim3(256), 0, s, flat_dev, exp_avg_dev, exp_avg_sq_dev, h->grad, h->nparam, h->state, beta1, beta2, eps, h->map, h->Wm);
     if (ppo_pack(h, s)) return 1;
   }
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_minibatch: launch failed");
   return 0;
 }
-// gradient of the last mini-batch, flat order: direction 0 copies it into grad_dev, 1 replaces it by grad_dev (after an all-reduce)
+// gradient of the last mini-batch in flat order followed by its mean KL, nparam + 1 floats: direction 0 copies them into grad_dev,
+// 1 replaces them by grad_dev (after an all-reduce and the division by the number of ranks)
 extern "C" int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream) {
   if (!h || !grad_dev) return nm_policy_set_error("nm_ppo_copy_grad: bad argument");
   PPO_CHK(hipSetDevice(h->device));
-  PPO_CHK(hipMemcpyAsync(direction ? h->grad : grad_dev, direction ? grad_dev : h->grad, (size_t)h->nparam * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  PPO_CHK(hipMemcpyAsync(direction ? h->grad : grad_dev, direction ? grad_dev : h->grad, ((size_t)h->nparam + 1) * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 // HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, gradient norm.

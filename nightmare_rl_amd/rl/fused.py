@@ -157,16 +157,34 @@ class FusedUpdate:
         if phase != 1:
             self.step_count += 1
 
-    def grad(self, out=None):
-        """The last mini-batch's gradient, flat parameter order (a copy on the device)."""
-        out = torch.empty_like(self.flat) if out is None else out
+    def grad_and_kl(self, out=None):
+        """[num_params + 1]: the last mini-batch's gradient in flat parameter order, then its mean KL (a copy on the device) - the
+        vector a data-parallel update all-reduces."""
+        out = torch.empty(self.flat.numel() + 1, device=self.device) if out is None else out
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._L.nm_ppo_copy_grad(self._h, out.data_ptr(), 0, stream))
         return out
 
-    def set_grad(self, g):
+    def grad(self):
+        return self.grad_and_kl()[:-1]
+
+    def set_grad_and_kl(self, g):
+        assert g.numel() == self.flat.numel() + 1 and g.is_contiguous() and g.dtype == torch.float32
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self._L.nm_ppo_copy_grad(self._h, g.contiguous().data_ptr(), 1, stream))
+        _lib.check(self._L.nm_ppo_copy_grad(self._h, g.data_ptr(), 1, stream))
+
+    def minibatch_data_parallel(self, *batch, hp, world):
+        """One mini-batch of a data-parallel update: local gradient, ONE all-reduce of gradient | KL (RCCL when the process group is
+        nccl; every rank then applies the identical step), the step."""
+        import torch.distributed as dist
+        self.minibatch(*batch, hp, phase=1)
+        if getattr(self, "_gbuf", None) is None:
+            self._gbuf = torch.empty(self.flat.numel() + 1, device=self.device)
+        self.grad_and_kl(self._gbuf)
+        dist.all_reduce(self._gbuf)
+        self._gbuf.div_(world)
+        self.set_grad_and_kl(self._gbuf)
+        self.minibatch(*batch, hp, phase=2)
 
     def read_state(self, reset_sums=True):
         """dict(lr, steps, kl, value_loss_sum, surrogate_loss_sum, minibatches, clip_coef, grad_norm); one stream synchronisation."""

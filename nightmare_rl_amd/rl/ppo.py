@@ -35,9 +35,10 @@ class PPO:
         self.fused = self.fused_update = None
         if (critic_obs_shape is None or critic_obs_shape[0] is None) and FusedCollector.supported(self.actor_critic, self.device):
             # the update first: it re-homes the parameters in one flat vector, which the collector then reads
-            if FusedUpdate.supported(self.actor_critic, self.device) and _world() == 1:
+            if FusedUpdate.supported(self.actor_critic, self.device):
                 self.fused_update = FusedUpdate(self.actor_critic, self.optimizer, self.device, self.learning_rate)
-            self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=torch.initial_seed() & 0xFFFFFFFF)
+            rank = dist.get_rank() if _world() > 1 else 0     # every rank draws its own action noise
+            self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=(torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF)
 
     def after_load(self):
         """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow."""
@@ -116,7 +117,11 @@ class PPO:
         fu = self.fused_update
         for (obs, _cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in \
                 self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            fu.minibatch(obs, actions, target_values.reshape(-1), advantages.reshape(-1), returns.reshape(-1), old_logp.reshape(-1), old_mu, old_sigma, hp)
+            batch = (obs, actions, target_values.reshape(-1), advantages.reshape(-1), returns.reshape(-1), old_logp.reshape(-1), old_mu, old_sigma)
+            if _world() > 1:
+                fu.minibatch_data_parallel(*batch, hp=hp, world=_world())
+            else:
+                fu.minibatch(*batch, hp)
         st = fu.read_state()                      # the one host synchronisation of the update
         self.learning_rate, self.last_kl = st["lr"], st["kl"]
         for g in self.optimizer.param_groups:

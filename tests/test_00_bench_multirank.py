@@ -28,3 +28,14 @@ def test_two_rank_bench_times_a_collective():
     assert out["config"]["envs_per_gpu"] == 1024
     assert abs(out["value"] - 2 * 1024 * 20 / (out["ms_per_step"] * 20 / 1e3)) < 1e-6 * out["value"]   # whole-job aggregate
     assert "cpu_baseline" not in out                                                                    # rank 0 at N=1 only
+
+
+def test_two_rank_fused_ppo_update_equals_the_single_process_update():
+    """The data-parallel update path of rl/ppo.py (FusedUpdate.minibatch_data_parallel: gradient | KL in ONE all-reduce per mini-batch)
+    with two ranks sharing the card over gloo: ranks stay bit-identical and match a full-batch single-process update."""
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "tests", "tools", "ppo_two_ranks.py")]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "PPO_TWO_RANKS_OK" in r.stdout
