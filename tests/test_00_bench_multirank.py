@@ -39,3 +39,16 @@ def test_two_rank_fused_ppo_update_equals_the_single_process_update():
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     assert "PPO_TWO_RANKS_OK" in r.stdout
+
+
+def test_two_rank_train_py_runs_the_fused_data_parallel_loop(tmp_path):
+    """BASELINE config 5's launch shape in miniature: train.py under torch.distributed.run, env ids sharded over the ranks, fused
+    collection per rank, data-parallel fused update."""
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29535", os.path.join(ROOT, "train.py"), "-e", "1024", "--iters", "4"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("it ")]
+    assert len(lines) == 4 and "nan" not in lines[-1], lines
+    assert "contacts_dropped': 0" in r.stdout
