@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel stats: bench"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bench -o run -- python3 $ROOT/bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_prof_bench.log 2>&1
 echo "== rocprof kernel stats: train"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o run -- python3 $ROOT/train.py -e 4096 --iters 12 > $OUT/${TAG}_prof_train.log 2>&1
 echo "== rocprof kernel stats + MFMA counters: mlp"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_mlp -o run -- python3 $ROOT/scripts/mlpbench.py > $OUT/${TAG}_prof_mlp.log 2>&1
-rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_mlp -o run -- python3 $ROOT/scripts/mlpbench.py > $OUT/${TAG}_pmc_mlp.log 2>&1
+rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_mlp -o run -- python3 $ROOT/scripts/mlpbench.py 4096 big > $OUT/${TAG}_pmc_mlp.log 2>&1
 for d in bench train mlp; do f=$(ls $OUT/${TAG}_prof_$d/*kernel_stats.csv $OUT/${TAG}_prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${d}_kernel_stats.csv && head -6 $OUT/${TAG}_${d}_kernel_stats.csv | cut -c1-200; done
 python $ROOT/scripts/pmc_summary.py $OUT/${TAG}_pmc_mlp k_mlp_fused > $OUT/${TAG}_pmc_mlp_summary.txt 2>&1; cat $OUT/${TAG}_pmc_mlp_summary.txt | head -12
 fi

@@ -4,7 +4,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nightmare_rl_amd.policy import ActorMLP
 torch.manual_seed(0)
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for dims in ([66, 256, 256, 18], [66, 54, 42, 30, 18], [66, 108, 84, 60, 19]):
+NETS = ([66, 256, 256, 18], [66, 54, 42, 30, 18], [66, 108, 84, 60, 19])
+if len(sys.argv) > 2:       # "big": BASELINE config 3's network only (one kernel shape per counter run)
+    NETS = NETS[:1] if sys.argv[2] == "big" else NETS[1:]
+for dims in NETS:
     net = ActorMLP(dims).cuda(); x = torch.randn(N, 66, device="cuda")
     with torch.no_grad():
         ref = net.torch_forward(x)
