@@ -166,6 +166,7 @@ template <class real, int G> struct ShW {
   alignas(16) real jrow[kMaxRow * kJRow];
 };
 #define NM_OFS(field) ((int)(offsetof(Sh<real>, field) / sizeof(real)))
+#define NM_IOFS(field) ((int)(offsetof(Sh<real>, field) / sizeof(int)))
 
 // ----------------------------------------------------------------------------------------- small algebra
 template <class A, class B, class C> NM_FN void cross3(A* r, const B* a, const C* b) {
@@ -2161,6 +2162,37 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   wave_sync();
 }
 
+// debug buffer of one env (measurement / tests only)
+template <class real> NM_FN void env_debug(Sh<real>& sh, const Args<real>& A, int env, int dropped) {
+  const V<int> lane = opaque_lane();
+  {
+    real* dbg = A.dbg + (size_t)env * kDbgN;
+    gstv(dbg, lane, ldsv(sh.qas, sel(lane < 24, lane, V<int>(0))), lane < 24);
+    gstv(dbg, lane + 24, ldsv(sh.qfs, sel(lane < 24, lane, V<int>(0))), lane < 24);
+    gstv(dbg, lane + 48, ldsv(sh.qfc, sel(lane < 24, lane, V<int>(0))), lane < 24);
+    gstv(dbg, lane + 72, ldsv(sh.sens, sel(lane < 13, lane, V<int>(0))), lane < 13);
+    gstv(dbg, lane + 88, ldsv(sh.cvb, sel(lane < 6, lane, V<int>(0))), lane < 6);
+    gstv(dbg, lane + 96, ldsv(sh.cdist(), sel(lane < kMaxCon, lane, V<int>(0))), lane < kMaxCon);
+    gstv(dbg, lane + 112, ldsv(sh.cpos(), sel(lane < 3 * kMaxCon, lane, V<int>(0))), lane < 3 * kMaxCon);
+    gstv(dbg, V<int>(160), to_real<real>(sh.ncon), lane == 0);
+    gstv(dbg, V<int>(161), to_real<real>(sh.nwarn), lane == 0);
+    gstv(dbg, V<int>(162), to_real<real>(dropped), lane == 0);
+    gstv(dbg, lane + 165, ldsv(sh.cnrm(), sel(lane < 6, lane, V<int>(0))), lane < 6);
+    gstv(dbg, lane + 150, to_real<real>(ldsv(sh.hcache, sel(lane < 7, lane, V<int>(0)))), lane < 7);
+    gstv(dbg, V<int>(158), to_real<real>(sh.hcache[7]), lane == 0);
+    gstv(dbg, V<int>(159), to_real<real>(sh.nhop), lane == 0);
+    gstv(dbg, V<int>(157), to_real<real>(sh.anypair), lane == 0);
+    gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
+    gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
+    gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);
+#ifdef NM_DEBUG_SOLVER
+    gstv(dbg, lane + 240, ldsv(sh.dbg_b, sel(lane < 4, lane, V<int>(0))), lane < 4);
+    gstv(dbg, lane + 244, ldsv(sh.dbg_a, sel(lane < 4, lane, V<int>(0))), lane < 4);
+    gstv(dbg, lane + 248, ldsv(sh.dbg_f0, sel(lane < 4, lane, V<int>(0))), lane < 4);
+#endif
+  }
+}
+
 // store one env's state, run the env epilogue (E3-E8). `live` = the slot holds a real env (last wave may be padded)
 template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, const Args<real>& A, int env,
                                             int dropped, bool live) {
@@ -2190,32 +2222,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     gstv(A.rec, lane + kNQ, ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0))), lane < kNV);
     gstv(A.rec, V<int>(kNQ + kNV), to_real<real>(sh.nwarn), lane == 0);
   }
-  if (A.dbg) {
-    real* dbg = A.dbg + (size_t)env * kDbgN;
-    gstv(dbg, lane, ldsv(sh.qas, sel(lane < 24, lane, V<int>(0))), lane < 24);
-    gstv(dbg, lane + 24, ldsv(sh.qfs, sel(lane < 24, lane, V<int>(0))), lane < 24);
-    gstv(dbg, lane + 48, ldsv(sh.qfc, sel(lane < 24, lane, V<int>(0))), lane < 24);
-    gstv(dbg, lane + 72, ldsv(sh.sens, sel(lane < 13, lane, V<int>(0))), lane < 13);
-    gstv(dbg, lane + 88, ldsv(sh.cvb, sel(lane < 6, lane, V<int>(0))), lane < 6);
-    gstv(dbg, lane + 96, ldsv(sh.cdist(), sel(lane < kMaxCon, lane, V<int>(0))), lane < kMaxCon);
-    gstv(dbg, lane + 112, ldsv(sh.cpos(), sel(lane < 3 * kMaxCon, lane, V<int>(0))), lane < 3 * kMaxCon);
-    gstv(dbg, V<int>(160), to_real<real>(sh.ncon), lane == 0);
-    gstv(dbg, V<int>(161), to_real<real>(sh.nwarn), lane == 0);
-    gstv(dbg, V<int>(162), to_real<real>(dropped), lane == 0);
-    gstv(dbg, lane + 165, ldsv(sh.cnrm(), sel(lane < 6, lane, V<int>(0))), lane < 6);
-    gstv(dbg, lane + 150, to_real<real>(ldsv(sh.hcache, sel(lane < 7, lane, V<int>(0)))), lane < 7);
-    gstv(dbg, V<int>(158), to_real<real>(sh.hcache[7]), lane == 0);
-    gstv(dbg, V<int>(159), to_real<real>(sh.nhop), lane == 0);
-    gstv(dbg, V<int>(157), to_real<real>(sh.anypair), lane == 0);
-    gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
-    gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
-    gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);
-#ifdef NM_DEBUG_SOLVER
-    gstv(dbg, lane + 240, ldsv(sh.dbg_b, sel(lane < 4, lane, V<int>(0))), lane < 4);
-    gstv(dbg, lane + 244, ldsv(sh.dbg_a, sel(lane < 4, lane, V<int>(0))), lane < 4);
-    gstv(dbg, lane + 248, ldsv(sh.dbg_f0, sel(lane < 4, lane, V<int>(0))), lane < 4);
-#endif
-  }
+  if (A.dbg) env_debug(sh, A, env, dropped);
   if ((dropped | sh.nwarn) && A.stat_cnt) {
 #ifdef NM_EMUL
     A.stat_cnt[1] += dropped; A.stat_cnt[2] += sh.nwarn;
@@ -2442,21 +2449,397 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
   }
 }
 
+// ---- G = 2: both envs of the wave at once, lanes 0..31 for env 0 and lanes 32..63 for env 1. The same instruction stream as
+// env_load / env_finish, executed once instead of twice: per-env scalars become per-lane values that are equal inside a half,
+// LDS addresses carry the half's image offset, sums over joints are half-wave sums (hsum32). What is genuinely scalar (episode
+// length as int64, the command RNG) stays scalar, once per half. Every HBM read of BOTH envs is in flight before the first wait.
+template <class real> NM_FN void env_load2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave) {
+  typedef V<real> vr;
+  constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real)), kSI = (int)(sizeof(Sh<real>) / sizeof(int));
+  const V<int> lane = opaque_lane();
+  const V<int> h = lane >> 5, hl = lane & 31;
+  const V<int> env0 = h + wave * 2;
+  const V<int> env = sel(env0 < V<int>(A.N), env0, V<int>(A.N - 1));   // a padded slot recomputes the last env; nothing of it is stored
+  real* rb = reinterpret_cast<real*>(&w.e[0]);
+  int* ib = reinterpret_cast<int*>(&w.e[0]);
+  const V<int> ho = h * kSR, hoi = h * kSI;
+  const VB l18 = hl < kNU;
+  const V<int> l18c = sel(l18, hl, V<int>(0));
+  const vr q_in = gldv(A.qpos, sel(hl < kNQ, hl, V<int>(0)) + env * kNQ);
+  const vr v_in = gldv(A.qvel, sel(hl < kNV, hl, V<int>(0)) + env * kNV);
+  const vr w_in = gldv(A.qwarm, sel(hl < kNV, hl, V<int>(0)) + env * kNV);
+  const V<int> hc_in = gldv(A.hullcache, sel(hl < 8, hl, V<int>(0)) + env * 8);
+  const V<float> a_in = gldv(A.actions, l18c + env * kNU);
+  vr cmd_in = vr(real(0)), eps_in = vr(real(0)), prev_act = vr(real(0)), prev_dofvel = vr(real(0)), dofpos_old = vr(real(0));
+#ifndef NM_EMUL
+  int64_t ep = 0;
+  uint32_t ctr_in = 0;
+#endif
+  if (!A.physics_only) {
+    cmd_in = gldv(A.cmd, sel(hl < 3, hl, V<int>(0)) + env * 3);
+    eps_in = gldv(A.epsum, sel(hl < kNREW, hl, V<int>(0)) + env * kNREW);
+#ifndef NM_EMUL
+    ep = gld1(A.eplen, (size_t)env);
+    ctr_in = gld1(A.rngctr, (size_t)env);
+#endif
+    prev_act = gldv(A.act, l18c + env * kNU);
+    prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
+    dofpos_old = gldv(A.dofpos, l18c + env * kNU);
+  }
+  stsv(rb, ho + (hl + NM_OFS(qpos)), q_in, hl < kNQ);
+  stsv(rb, ho + (hl + NM_OFS(qvel)), v_in, hl < kNV);
+  stsv(rb, ho + (hl + NM_OFS(warm)), w_in, hl < kNV);
+  stsv(ib, hoi + (hl + NM_IOFS(hcache)), hc_in, hl < 8);
+  w.e[0].nwarn = 0; w.e[1].nwarn = 0;
+  w.e[0].nhop = 0; w.e[1].nhop = 0;
+  // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
+  V<float> af = a_in * M.action_scale;
+  af = vmin(vmax(af, V<float>(-M.clip_actions)), V<float>(M.clip_actions));
+  vr act;
+  vr defp;
+  {
+    V<int> m3 = hl % 3;
+    defp = sel(m3 == 1, vr(M.default_pos[1]), sel(m3 == 0, vr(M.default_pos[0]), vr(M.default_pos[2])));
+  }
+#ifdef NM_EMUL
+  for (int i = 0; i < NM_WAVE; i++) act.v[i] = (real)af.v[i];
+#else
+  act = (real)af;
+#endif
+  if (!A.physics_only) {
+    stsv(rb, ho + (hl + NM_OFS(ecmd)), cmd_in, hl < 3);
+    stsv(rb, ho + (hl + NM_OFS(eepsum)), eps_in, hl < kNREW);
+#ifdef NM_EMUL
+    for (int hh = 0; hh < 2; hh++) {
+      const int e = env.v[32 * hh];
+      const int64_t ep = A.eplen[e];
+      w.e[hh].eplen_lo = (int)(uint32_t)(ep & 0xffffffffll);
+      w.e[hh].eplen_hi = (int)(ep >> 32);
+      w.e[hh].ectr = A.rngctr[e];
+    }
+#else
+    stsv(ib, hoi + NM_IOFS(eplen_lo), (int)(uint32_t)(ep & 0xffffffffll), hl == 0);
+    stsv(ib, hoi + NM_IOFS(eplen_hi), (int)(ep >> 32), hl == 0);
+    stsv(ib, hoi + NM_IOFS(ectr), (int)ctr_in, hl == 0);
+#endif
+    stsv(rb, ho + (hl + NM_OFS(ctrl)), ((act - defp) - dofpos_old) * M.p_gain, l18);
+  } else {
+    wave_sync();
+    stsv(rb, ho + (hl + NM_OFS(ctrl)), ((act - defp) - ldsv(rb, ho + (l18c + (7 + NM_OFS(qpos))))) * M.p_gain, l18);
+  }
+  stsv(rb, ho + (hl + NM_OFS(eact)), act, l18); stsv(rb, ho + (hl + NM_OFS(epact)), prev_act, l18); stsv(rb, ho + (hl + NM_OFS(epdv)), prev_dofvel, l18);
+  wave_sync();
+}
+
+template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave, int dropped) {
+  typedef V<real> vr;
+  constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real)), kSI = (int)(sizeof(Sh<real>) / sizeof(int));
+  const V<int> lane = opaque_lane();
+  const V<int> h = lane >> 5, hl = lane & 31;
+  const VB h1 = h != 0;
+  const V<int> env = h + wave * 2;
+  const VB live = env < V<int>(A.N);
+  const V<int> envc = sel(live, env, V<int>(A.N - 1));
+  const bool lives[2] = {wave * 2 < A.N, wave * 2 + 1 < A.N};
+  const real* rb = reinterpret_cast<const real*>(&w.e[0]);
+  const int* ib = reinterpret_cast<const int*>(&w.e[0]);
+  const V<int> ho = h * kSR, hoi = h * kSI;
+#define SHR(field, idx) ldsv(rb, ho + ((idx) + NM_OFS(field)))
+#define SHI(field, idx) ldsv(ib, hoi + ((idx) + NM_IOFS(field)))
+  const VB l18 = hl < kNU;
+  const V<int> l18c = sel(l18, hl, V<int>(0));
+  const vr act = SHR(eact, l18c), prev_act = SHR(epact, l18c), prev_dofvel = SHR(epdv, l18c);
+  vr defp;
+  {
+    V<int> m3 = hl % 3;
+    defp = sel(m3 == 1, vr(M.default_pos[1]), sel(m3 == 0, vr(M.default_pos[0]), vr(M.default_pos[2])));
+  }
+  // ---- store physics state
+  const V<int> nwarn = SHI(nwarn, V<int>(0));
+  {
+    const V<int> hc = SHI(hcache, sel(hl < 8, hl, V<int>(0)));
+    const vr q = SHR(qpos, sel(hl < kNQ, hl, V<int>(0))), v = SHR(qvel, sel(hl < kNV, hl, V<int>(0))), wq = SHR(warm, sel(hl < kNV, hl, V<int>(0)));
+    gstv(A.hullcache, hl + env * 8, hc, live & (hl < 8));
+    gstv(A.qpos, hl + env * kNQ, q, live & (hl < kNQ));
+    gstv(A.qvel, hl + env * kNV, v, live & (hl < kNV));
+    gstv(A.qwarm, hl + env * kNV, wq, live & (hl < kNV));
+    if (A.rec) {
+      const VB r = live & (env == V<int>(A.rec_env));
+      gstv(A.rec, hl, q, r & (hl < kNQ));
+      gstv(A.rec, hl + kNQ, v, r & (hl < kNV));
+      gstv(A.rec, V<int>(kNQ + kNV), to_real<real>(nwarn), r & (hl == 0));
+    }
+  }
+  if (A.dbg) {
+    if (lives[0]) env_debug(w.e[0], A, wave * 2, dropped);
+    if (lives[1]) env_debug(w.e[1], A, wave * 2 + 1, 0);
+  }
+  if (A.stat_cnt && (dropped != 0 || wany(live & (nwarn != 0)))) {
+#ifdef NM_EMUL
+    A.stat_cnt[1] += dropped;
+    for (int hh = 0; hh < 2; hh++) if (lives[hh]) A.stat_cnt[2] += nwarn.v[32 * hh];
+#else
+    if (threadIdx.x == 0 && dropped) nm_consume(atomicAdd(A.stat_cnt + 1, dropped));
+    if (hl == 0 && live && nwarn) nm_consume(atomicAdd(A.stat_cnt + 2, nwarn));
+#endif
+  }
+  if (A.physics_only) return;
+  NM_ESTAMP(11);
+
+  // ---- E3 (env.py:212-232): frame transforms with the POST-integration quaternion, stale cvel/sensors
+  int64_t ep[2];
+  uint32_t ctr[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; hh++) {
+    ep[hh] = (((int64_t)w.e[hh].eplen_hi << 32) | (int64_t)(uint32_t)w.e[hh].eplen_lo) + 1;
+    ctr[hh] = w.e[hh].ectr;
+  }
+  vr bq[4] = {SHR(qpos, V<int>(3)), -SHR(qpos, V<int>(4)), -SHR(qpos, V<int>(5)), -SHR(qpos, V<int>(6))};  // mju_negQuat
+  auto rot = [&](vr* r, const vr* v) {  // mju_rotVecQuat
+    vr tx = real(2) * (bq[2] * v[2] - bq[3] * v[1]), ty = real(2) * (bq[3] * v[0] - bq[1] * v[2]), tz = real(2) * (bq[1] * v[1] - bq[2] * v[0]);
+    r[0] = v[0] + bq[0] * tx + (bq[2] * tz - bq[3] * ty);
+    r[1] = v[1] + bq[0] * ty + (bq[3] * tx - bq[1] * tz);
+    r[2] = v[2] + bq[0] * tz + (bq[1] * ty - bq[2] * tx);
+  };
+  vr blv[3], bav[3], pg[3];
+  {
+    vr lin[3] = {SHR(cvb, V<int>(3)), SHR(cvb, V<int>(4)), SHR(cvb, V<int>(5))}, ang[3] = {SHR(cvb, V<int>(0)), SHR(cvb, V<int>(1)), SHR(cvb, V<int>(2))};
+    vr gv[3] = {vr(real(0)), vr(real(0)), vr(-M.grav)};
+    rot(blv, lin); rot(bav, ang); rot(pg, gv);
+  }
+  vr dofpos = SHR(qpos, l18c + 7), dofvel = SHR(qvel, l18c + 6);
+  vr tib[6], feet[6], body = SHR(sens, V<int>(12));
+#pragma unroll
+  for (int l = 0; l < 6; l++) {
+    feet[l] = SHR(sens, V<int>(6 + l));
+    tib[l] = sel(feet[l] == vr(real(0)), SHR(sens, V<int>(l)), vr(real(0)));  // env.py:232
+  }
+  // ---- E4 (env.py:235-236, 321-333): periodic command resample - scalar, per half
+  vr cmd[3] = {SHR(ecmd, V<int>(0)), SHR(ecmd, V<int>(1)), SHR(ecmd, V<int>(2))};
+  auto resample = [&](int hh, int which) {
+    const int e = wave * 2 + hh;
+    real ux, uy;
+    if (A.cmd_u) { ux = gld1(A.cmd_u, (size_t)(e * 4 + 2 * which)); uy = gld1(A.cmd_u, (size_t)(e * 4 + 2 * which + 1)); }
+    else {
+      ux = (real)rand_u24_bits(A.seed, (uint64_t)(A.env_offset + e), ctr[hh]) * real(1.0 / 16777216.0);
+      uy = (real)rand_u24_bits(A.seed, (uint64_t)(A.env_offset + e), ctr[hh] + 1) * real(1.0 / 16777216.0);
+      ctr[hh] += 2;
+    }
+    real c0 = ux * real(2) * M.max_lin_x - M.max_lin_x, c1 = real(0), c2 = uy * real(2) * M.max_ang - M.max_ang;
+    real keep = vsqrt(c0 * c0 + c1 * c1) > real(0.02) ? real(1) : real(0);
+    c0 = c0 * keep; c1 = c1 * keep;
+    const VB mine = hh ? h1 : !h1;
+    cmd[0] = sel(mine, vr(c0), cmd[0]); cmd[1] = sel(mine, vr(c1), cmd[1]); cmd[2] = sel(mine, vr(c2), cmd[2]);
+  };
+  bool tos[2];
+#pragma unroll
+  for (int hh = 0; hh < 2; hh++) {
+    bool due;
+    if (ep[hh] >= 0 && ep[hh] < (1 << 22)) {   // episode lengths are a few thousand steps: float quotient + exact integer remainder
+      const int e32 = (int)ep[hh], R = M.resample_every;
+      const int q = (int)((float)e32 / (float)R);
+      const int r = e32 - q * R;             // q is off by at most one
+      due = r == 0 || r == R || r == -R;
+    } else due = ep[hh] % M.resample_every == 0;
+    if (due && lives[hh]) resample(hh, 0);
+    tos[hh] = (real)ep[hh] > M.max_ep_len;
+  }
+  // ---- E5 (env.py:239-258): termination
+  const VB time_out = (h1 & VB(tos[1])) | (!h1 & VB(tos[0]));
+  VB reset = time_out;
+  {
+    vr fm = feet[0];
+#pragma unroll
+    for (int l = 1; l < 6; l++) fm = vmax(fm, feet[l]);
+    reset = reset | (fm > vr(M.term_force));
+    if ((M.tibia_mode == 2) | (M.body_mode == 2)) {   // env.py:248-251
+      vr tm = tib[0];
+#pragma unroll
+      for (int l = 1; l < 6; l++) tm = vmax(tm, tib[l]);
+      if (M.tibia_mode == 2) reset = reset | (tm > vr(M.tibia_max));
+      if (M.body_mode == 2) reset = reset | (body > vr(M.body_max));
+    }
+    vr nrm = vsqrt(pg[0] * pg[0] + pg[1] * pg[1] + pg[2] * pg[2]);
+    if (sizeof(real) == 8) reset = reset | (vacos(-pg[2] / nrm) > vr(real(1.0471975511965976)));
+    else reset = reset | ((-pg[2] / nrm) <= vr(real(0.5)));
+  }
+  NM_ESTAMP(12);
+  // ---- E6 (env.py:274, 335-371): reset BEFORE rewards/obs: qpos0, zero velocity, new command, episode stats
+  vr epsum = SHR(eepsum, sel(hl < kNREW, hl, V<int>(0)));
+  const VB resetL = reset & live;
+  const uint64_t rmask = ballot(resetL);
+  if (rmask) {
+    gstv(A.qpos, hl + env * kNQ, ldsv(M.qpos0, sel(hl < kNQ, hl, V<int>(0))), resetL & (hl < kNQ));
+    gstv(A.qvel, hl + env * kNV, real(0), resetL & (hl < kNV));
+#pragma unroll
+    for (int hh = 0; hh < 2; hh++)
+      if ((rmask >> (32 * hh)) & 1) { resample(hh, 1); ep[hh] = 0; }
+#ifdef NM_EMUL
+    for (int hh = 0; hh < 2; hh++)
+      if ((rmask >> (32 * hh)) & 1) {
+        for (int k = 0; k < kNREW; k++) A.stat_sum[k] += epsum.v[32 * hh + k];
+        A.stat_cnt[0] += 1;
+      }
+#else
+    if (resetL && hl < kNREW) nm_consume(atomicAdd(A.stat_sum + hl, epsum));
+    if (resetL && hl == 0) {
+      nm_consume(atomicAdd(A.stat_cnt, 1));
+      if (time_out && A.to_list) nm_consume(atomicExch(A.to_list + atomicAdd(A.nto, 1), env));
+    }
+#endif
+    epsum = sel(resetL, vr(real(0)), epsum);
+  }
+  NM_ESTAMP(13);
+  // ---- E7 (env.py:277-288, 399-497): rewards (alphabetical, termination last)
+  vr rt[kNREW];
+#pragma unroll
+  for (int k = 0; k < kNREW; k++) rt[k] = vr(real(0));
+  {
+    vr da = prev_act - act;
+    rt[R_ACTION_RATE] = hsum32(sel(l18, da * da, vr(real(0)))) * M.rew_scale[R_ACTION_RATE];
+    vr sumt = ((tib[0] + tib[1]) + (tib[2] + tib[3])) + (tib[4] + tib[5]);
+    if ((M.tibia_mode != 1) | (M.body_mode != 1)) {   // env.py:479-485: each part counts only in mode 1
+      sumt = M.tibia_mode == 1 ? sumt : vr(real(0));
+      body = M.body_mode == 1 ? body : vr(real(0));
+    }
+    rt[R_BODY_CONTACT] = (sumt + body) * M.rew_scale[R_BODY_CONTACT];
+    vr dp = dofpos - defp;
+    rt[R_DEFAULT_POS] = hsum32(sel(l18, dp * dp, vr(real(0)))) * M.rew_scale[R_DEFAULT_POS];
+    vr acc = (dofvel - prev_dofvel) / M.dt;
+    rt[R_DOF_ACC] = hsum32(sel(l18, acc * acc, vr(real(0)))) * M.rew_scale[R_DOF_ACC];
+    rt[R_ORIENTATION] = (pg[0] * pg[0] + pg[1] * pg[1]) * M.rew_scale[R_ORIENTATION];
+    vr ea = (cmd[2] - bav[2]) * (cmd[2] - bav[2]);
+    rt[R_TRACK_ANG] = vexp(-ea / M.sigma) * M.rew_scale[R_TRACK_ANG];
+    vr el = (cmd[0] - blv[0]) * (cmd[0] - blv[0]) + (cmd[1] - blv[1]) * (cmd[1] - blv[1]);
+    rt[R_TRACK_LIN] = vexp(-el / M.sigma) * M.rew_scale[R_TRACK_LIN];
+    rt[R_TERMINATION] = sel(reset & !time_out, vr(M.rew_scale[R_TERMINATION]), vr(real(0)));
+    if (M.rew_extra) {   // the terms config.py:88-95 ships with scale 0: one uniform branch in the default configuration
+      rt[R_ANG_VEL_XY] = (bav[0] * bav[0] + bav[1] * bav[1]) * M.rew_scale[R_ANG_VEL_XY];                  // env.py:403-405
+      vr dh = SHR(bh, V<int>(0)) - M.base_h_target;
+      rt[R_BASE_HEIGHT] = dh * dh * M.rew_scale[R_BASE_HEIGHT];                                            // env.py:411-413
+      rt[R_DOF_VEL] = hsum32(sel(l18, dofvel * dofvel, vr(real(0)))) * M.rew_scale[R_DOF_VEL];              // env.py:419-421
+      rt[R_LIN_VEL_Z] = blv[2] * blv[2] * M.rew_scale[R_LIN_VEL_Z];                                        // env.py:399-401
+      vr still = sel(vsqrt(cmd[0] * cmd[0] + cmd[1] * cmd[1]) < vr(real(0.01)), vr(real(1)), vr(real(0)));
+      rt[R_STAND_STILL] = hsum32(sel(l18, vabs(dp), vr(real(0)))) * still * M.rew_scale[R_STAND_STILL];     // env.py:487-489
+      const VB l6 = hl < kNLEG;
+      const V<int> l6c = sel(l6, hl, V<int>(0));
+      const vr ff = SHR(sens, l6c + 6);
+      vr over = sel(ff > vr(M.max_contact_force), ff - M.max_contact_force, vr(real(0)));
+      rt[R_FEET_CONTACT] = hsum32(sel(l6, over * over, vr(real(0)))) * M.rew_scale[R_FEET_CONTACT];         // env.py:491-493
+      if (M.rew_scale[R_FEET_AIR_TIME] != real(0)) {   // env.py:458-477; stateful: runs only while it is in the reward table
+        vr air = gldv(A.feetair, l6c + envc * kNLEG);
+        const V<int> fl = gldv(A.feetflags, envc);
+        air = sel(reset, vr(real(0)), air);            // reset_idx zeroes feet_air_time (env.py:359) before the rewards run
+        const VB contact = ff > vr(real(1));
+        const VB filt = contact | (((fl >> l6c) & 1) != 0);
+        const VB lastf = ((fl >> (l6c + kNLEG)) & 1) != 0;
+        air = air + M.dt;
+        air = sel(filt == lastf, air, vr(real(0)));    // reset air time if the filtered contact changes
+        const vr single = sel(air > vr(real(1)), air - real(1), vr(real(0))) + sel(air < vr(real(0.5)), real(0.5) - air, vr(real(0)));
+        rt[R_FEET_AIR_TIME] = hsum32(sel(l6, single * single, vr(real(0)))) * M.rew_scale[R_FEET_AIR_TIME];
+        gstv(A.feetair, l6c + env * kNLEG, air, live & l6);
+        const uint64_t bc = ballot(l6 & contact), bf = ballot(l6 & filt);
+        const int nf0 = (int)((bc & 63) | ((bf & 63) << kNLEG)), nf1 = (int)(((bc >> 32) & 63) | (((bf >> 32) & 63) << kNLEG));
+        gstv(A.feetflags, env, sel(h1, V<int>(nf1), V<int>(nf0)), live & (hl == 0));
+      }
+    }
+  }
+  vr rew = vr(real(0));
+#pragma unroll
+  for (int k = 0; k < kNREW; k++) rew = rew + rt[k];
+  {
+    vr add = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < kNREW; k++) add = sel(hl == k, rt[k], add);
+    gstv(A.epsum, hl + env * kNREW, epsum + add, live & (hl < kNREW));
+  }
+  NM_ESTAMP(14);
+  // ---- E8 (env.py:291-311): observation (66), clipped, float32
+  {
+    vr head[12] = {blv[0] * M.obs_lin, blv[1] * M.obs_lin, blv[2] * M.obs_lin, bav[0] * M.obs_ang, bav[1] * M.obs_ang, bav[2] * M.obs_ang,
+                   pg[0], pg[1], pg[2], cmd[0] * M.obs_lin, cmd[1] * M.obs_lin, cmd[2] * M.obs_ang};
+    vr o = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < 12; k++) o = sel(hl == k, head[k], o);
+    auto put = [&](const vr& x0, const V<int>& idx, const VB& m0) {
+      const VB m = m0 & live;
+      vr x = x0;
+      if (A.noise_vec) {  // env.py:304-305: + (2 U[0,1) - 1) * noise_scale_vec before the clip
+        auto nz = [&](int k, int e) {
+          real u = A.noise_u ? gld1(A.noise_u, (size_t)e * kNOBS + k)
+                             : (real)rand_u24_bits(A.seed + kNoiseKey, (uint64_t)(A.env_offset + e), (uint32_t)(A.noise_step * kNOBS + k)) * real(1.0 / 16777216.0);
+          return (real(2) * u - real(1)) * gld1(A.noise_vec, (size_t)k);
+        };
+#ifdef NM_EMUL
+        for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) x.v[i] = x.v[i] + nz(idx.v[i], env.v[i]);
+#else
+        if (m) x = x + nz(idx, env);
+#endif
+      }
+      vr cx = vmin(vmax(x, vr(-M.clip_obs)), vr(M.clip_obs));
+#ifdef NM_EMUL
+      for (int i = 0; i < NM_WAVE; i++) if (m.v[i]) A.obs[(size_t)env.v[i] * kNOBS + idx.v[i]] = (float)cx.v[i];
+#else
+      if (m) gst1(A.obs, (size_t)env * kNOBS + idx, (float)cx);
+#endif
+    };
+    put(o, hl, hl < 12);
+    put((dofpos - defp) * M.obs_dofpos, hl + 12, l18);
+    put(dofvel * M.obs_dofvel, hl + 30, l18);
+    put(act, hl + 48, l18);
+  }
+  NM_ESTAMP(15);
+  // ---- buffers the reference keeps between steps
+  gstv(A.dofpos, hl + env * kNU, dofpos, live & l18);
+  gstv(A.dofvel, hl + env * kNU, dofvel, live & l18);
+  gstv(A.act, hl + env * kNU, act, live & l18);
+  {
+    vr cv = sel(hl == 0, cmd[0], sel(hl == 1, cmd[1], cmd[2]));
+    gstv(A.cmd, hl + env * 3, cv, live & (hl < 3));
+  }
+#ifdef NM_EMUL
+  for (int hh = 0; hh < 2; hh++)
+    if (lives[hh]) {
+      const int e = wave * 2 + hh, l0 = 32 * hh;
+      A.eplen[e] = ep[hh]; A.rngctr[e] = ctr[hh]; A.rew[e] = (float)rew.v[l0];
+      A.done[e] = (int64_t)(reset.v[l0] ? 1 : 0); A.timeout_now[e] = time_out.v[l0] ? 1.0f : 0.0f;
+    }
+#else
+  if (hl == 0 && live) {
+    gst1(A.eplen, (size_t)env, h1 ? ep[1] : ep[0]);
+    gst1(A.rngctr, (size_t)env, h1 ? ctr[1] : ctr[0]);
+    gst1(A.rew, (size_t)env, (float)rew);
+    gst1(A.done, (size_t)env, (int64_t)(reset ? 1 : 0));
+    gst1(A.timeout_now, (size_t)env, time_out ? 1.0f : 0.0f);
+  }
+#endif
+#undef SHR
+#undef SHI
+}
+
 // one wavefront = G consecutive envs (E2, env.py:200: mj_step(model, data, decimation) between load and epilogue)
 template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave) {
   nm_stamp(-1);
+  if constexpr (G == 2) {
+    env_load2(w, M, A, wave);
+  } else {
 #pragma unroll
-  for (int e = 0; e < G; e++) {
-    int env = wave * G + e;
-    env_load(w.e[e], M, A, env < A.N ? env : A.N - 1);
+    for (int e = 0; e < G; e++) {
+      int env = wave * G + e;
+      env_load(w.e[e], M, A, env < A.N ? env : A.N - 1);
+    }
   }
   nm_stamp(0);
   int dropped = 0;
   for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, A.ablate);
+  if constexpr (G == 2) {
+    env_finish2(w, M, A, wave, dropped);
+  } else {
 #pragma unroll
-  for (int e = 0; e < G; e++) {
-    int env = wave * G + e;
-    env_finish(w.e[e], M, A, env, e == 0 ? dropped : 0, env < A.N);
+    for (int e = 0; e < G; e++) {
+      int env = wave * G + e;
+      env_finish(w.e[e], M, A, env, e == 0 ? dropped : 0, env < A.N);
+    }
   }
   nm_stamp(10);
 }

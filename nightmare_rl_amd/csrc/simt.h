@@ -103,6 +103,15 @@ template <class T> NM_FN T wsum(T x) {
   x = x + dpp<NM_DPP_ROW_MIRROR>(x);
   return (rdlane(x, 0) + rdlane(x, 16)) + (rdlane(x, 32) + rdlane(x, 48));
 }
+// sum inside each half of the wave (lanes 0..31 | 32..63); every lane gets its half's total. Same association order as wsum
+template <class T> NM_FN T hsum32(T x) {
+  x = x + dpp<NM_DPP_QUAD_XOR1>(x);
+  x = x + dpp<NM_DPP_QUAD_XOR2>(x);
+  x = x + dpp<NM_DPP_HALF_MIRROR>(x);
+  x = x + dpp<NM_DPP_ROW_MIRROR>(x);
+  const T s0 = rdlane(x, 0) + rdlane(x, 16), s1 = rdlane(x, 32) + rdlane(x, 48);
+  return (threadIdx.x & 32) ? s1 : s0;
+}
 NM_FN bool wany(bool c) { return __ballot(c) != 0ull; }
 // number of set bits of the wave-uniform mask m below this lane (v_mbcnt)
 NM_FN int lane_rank(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
@@ -242,6 +251,12 @@ template <class T> NM_FN T wsum8(V<T> x) {
 template <class T> NM_FN T wsum(V<T> x) {
   x = x + shfl_xor(x, 1); x = x + shfl_xor(x, 2); x = x + half_mirror(x); x = x + row_mirror(x);
   return (x.v[0] + x.v[16]) + (x.v[32] + x.v[48]);
+}
+template <class T> NM_FN V<T> hsum32(V<T> x) {
+  x = x + shfl_xor(x, 1); x = x + shfl_xor(x, 2); x = x + half_mirror(x); x = x + row_mirror(x);
+  const T s0 = x.v[0] + x.v[16], s1 = x.v[32] + x.v[48];
+  V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = i < 32 ? s0 : s1;
+  return r;
 }
 NM_FN bool wany(const VB& c) { for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) return true; return false; }
 NM_FN V<int> lane_rank(uint64_t m) { V<int> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = __builtin_popcountll(m & ((1ull << i) - 1ull)); return r; }
