@@ -1557,6 +1557,332 @@ template <class real> NM_COLD void stage_constraint_pairs(Sh<real>& sh, real* jr
   stage_constraint_body<real, true>(sh, jrow, M, last, nosweep);
 }
 
+// =========================================================================================  stage C, two envs at once
+// Floor-only envs with 1..kMaxCon2 contacts each (the common case once a robot stands): the wave's two envs go through the
+// constraint stage TOGETHER, lanes 0..31 = rows of env 0, lanes 32..63 = rows of env 1. Same arithmetic in the same order as
+// stage_constraint_body<real, false> per env (half-wave sums keep wsum's association), so the results are identical; what changes is
+// the cost: one pass whose length is max(ncon0, ncon1) instead of two passes of ncon0 + ncon1. Per-env scalars become per-lane
+// values (equal inside a half), LDS addresses carry the half's image offset, a row's broadcast is two v_readlane + a select, the
+// solvers' early exits become per-half run masks. The A matrix is 32 VGPRs here.
+constexpr int kMaxCon2 = 8, kMaxRow2 = 4 * kMaxCon2;
+#ifdef NM_EMUL
+inline long& nm_emul_together() { static long n = 0; return n; }   // host emulation only: how often the two-env pass ran (tests assert it did)
+#endif
+template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<real>& M, bool last, bool nosweep) {
+  typedef V<real> vr;
+  constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real)), kSI = (int)(sizeof(Sh<real>) / sizeof(int));
+  const V<int> lane = lane_id();
+  const V<int> h = lane >> 5, hl = lane & 31;
+  const VB h1 = h != 0;
+  real* rbw = reinterpret_cast<real*>(&w.e[0]);
+  int* ibw = reinterpret_cast<int*>(&w.e[0]);
+  const real* rb = rbw;
+  const int* ib = ibw;
+  real* jrow = w.jrow;
+  const V<int> ho = h * kSR, hoi = h * kSI, jh = h * (kMaxRow2 * kJRow);
+  const int oLeg = NM_OFS(legtmp);
+  const int oCleg = (int)((offsetof(Sh<real>, legtmp) + 7 * kMaxConBig * sizeof(real)) / sizeof(int));
+#define SHR(field, idx) ldsv(rb, ho + ((idx) + NM_OFS(field)))
+#define SHI(field, idx) ldsv(ib, hoi + ((idx) + NM_IOFS(field)))
+#define RDL(x, i) sel(h1, vr(rdlane(x, kMaxRow2 + (i))), vr(rdlane(x, (i))))
+  const int n0 = uniform(w.e[0].ncon), n1 = uniform(w.e[1].ncon), nmax = vmax(n0, n1);
+  const V<int> nconv = sel(h1, V<int>(n1), V<int>(n0)), nefc = nconv * 4;
+  const VB act = hl < nefc;
+  const V<int> c = sel(act, hl >> 2, V<int>(0));
+  const V<int> sg = hl & 1;
+  vr cp[3] = {ldsv(rb, ho + (c * 3 + oLeg)), ldsv(rb, ho + (c * 3 + (oLeg + 1))), ldsv(rb, ho + (c * 3 + (oLeg + 2)))};
+  vr dist = ldsv(rb, ho + (c + (oLeg + 6 * kMaxConBig)));
+  V<int> L = ldsv(ib, hoi + (c + oCleg));
+  const VB onleg = L >= 0;
+  const V<int> Lc = vmax(L, V<int>(0));
+  const V<int> q4 = hl & 3;
+  vr smu = sel(sg == 0, vr(M.mu), vr(-M.mu));
+  vr nrm[3] = {vr(real(0)), vr(real(0)), vr(real(1))};
+  vr e[3] = {sel(q4 == 2, vr(real(-1)), vr(real(0))), sel(q4 == 1, vr(real(1)), vr(real(0))), sel((q4 == 0) | (q4 == 3), vr(real(1)), vr(real(0)))};
+  // frame-axis Jacobian row: base translation, base rotation (body axes), the 3 hinges of the contact's own leg
+  vr Fb[6], Fl[3];
+  {
+    vr m[3];
+    cross3(m, cp, e);  // (p - O) x e
+    Fb[0] = e[0]; Fb[1] = e[1]; Fb[2] = e[2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) Fb[3 + j] = SHR(Rb, V<int>(j)) * m[0] + SHR(Rb, V<int>(3 + j)) * m[1] + SHR(Rb, V<int>(6 + j)) * m[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vr a[3], r[3], rel[3], mm[3];
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        a[j] = SHR(axs, Lc * 9 + (3 * k + j));
+        r[j] = SHR(anc, Lc * 9 + (3 * k + j));
+        rel[j] = cp[j] - r[j];
+      }
+      cross3(mm, rel, e);
+      Fl[k] = sel(onleg, dot3<vr>(a, mm), vr(real(0)));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) Fb[j] = sel(act, Fb[j], vr(real(0)));
+#pragma unroll
+  for (int k = 0; k < 3; k++) Fl[k] = sel(act, Fl[k], vr(real(0)));
+  vr uF[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    uF[j] = Fb[j];
+#pragma unroll
+    for (int k = 0; k < 3; k++) uF[j] = uF[j] - SHR(W, Lc * 18 + (6 * k + j)) * Fl[k];
+  }
+  // publish the frame rows (rows 4c, 4c+1, 4c+2 of the half's part of the buffer = n, t1, t2 of contact c)
+#pragma unroll
+  for (int j = 0; j < 6; j++) stsv(jrow, lane * kJRow + j, uF[j], VB(true));
+#pragma unroll
+  for (int k = 0; k < 3; k++) stsv(jrow, lane * kJRow + (6 + k), Fl[k], VB(true));
+  // own pyramid row J = J(n) + smu J(t_k): quad lane 0 holds n, lanes 1 / 2 hold t1 / t2
+  vr Jb[6], Jl[3];
+#pragma unroll
+  for (int j = 0; j < 6; j++) Jb[j] = quad<0x00>(Fb[j]) + smu * quad<0xA5>(Fb[j]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) Jl[k] = quad<0x00>(Fl[k]) + smu * quad<0xA5>(Fl[k]);
+  vr u[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) u[j] = quad<0x00>(uF[j]) + smu * quad<0xA5>(uF[j]);
+
+  // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
+  vr imp;
+  {
+    vr x = vabs(dist) / M.si_width;
+    vr ylo, yhi;
+    if (M.si_power == real(2)) {
+      vr omx = vmax(vr(real(1)) - x, vr(real(0)));
+      ylo = (x * x) / M.si_mid;
+      yhi = vr(real(1)) - (omx * omx) / (real(1) - M.si_mid);
+    } else {
+      ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
+      yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
+    }
+    vr y = sel(x <= vr(M.si_mid), ylo, yhi);
+    imp = M.si_d0 + y * (M.si_dmax - M.si_d0);
+    imp = sel(x >= vr(real(1)), vr(M.si_dmax), imp);
+    imp = sel(x <= vr(real(0)), vr(M.si_d0), imp);
+  }
+  vr invw = ldsv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
+  vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
+  vr Dd = vr(real(1)) / Rr;
+  vr vel = vr(real(0)), jas = vr(real(0)), jaw = vr(real(0));
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    vel += Jb[j] * SHR(qvel, V<int>(j)); jas += Jb[j] * SHR(qas, V<int>(j)); jaw += Jb[j] * SHR(warm, V<int>(j));
+  }
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    V<int> di = Lc * 3 + (6 + k);
+    vel += Jl[k] * SHR(qvel, di); jas += Jl[k] * SHR(qas, di); jaw += Jl[k] * SHR(warm, di);
+  }
+  vr aref = -M.solref_B * vel - M.solref_K * imp * dist;
+  vr bb = jas - aref;
+
+  // this lane's side of the projection: t = M_l^-1 Jl (own leg), xb = S^-1 u
+  vr t[3], xb[6];
+  {
+    vr Mi[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) Mi[j] = SHR(Minv, Lc * 6 + j);
+    ldl3_solve(t, Mi, Jl);
+    vr Lbv[15], Dbv[6];
+#pragma unroll
+    for (int j = 0; j < 15; j++) Lbv[j] = SHR(Lb, V<int>(j));
+#pragma unroll
+    for (int j = 0; j < 6; j++) Dbv[j] = SHR(Dbi, V<int>(j));
+#pragma unroll
+    for (int j = 0; j < 6; j++) xb[j] = u[j];
+    ldl6_solve(Lbv, Dbv, xb);
+  }
+  wave_sync();
+  vr A[kMaxRow2];
+#pragma unroll
+  for (int i = 0; i < kMaxRow2; i++) A[i] = vr(real(0));
+  auto build_contact = [&](auto ccT) {
+    constexpr int cc = decltype(ccT)::value;
+    if (cc < nmax) {
+      const V<int> Lcc = ldsv(ib, hoi + (cc + oCleg));
+      const VB same = onleg & (L == Lcc);
+      const VB has = V<int>(cc) < nconv;            // this half's env has contact cc
+      vr a3[3];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const V<int> jr = jh + (4 * cc + r) * kJRow;
+        vr a = ldsv(jrow, jr) * xb[0] + ldsv(jrow, jr + 1) * xb[1] + ldsv(jrow, jr + 2) * xb[2] + ldsv(jrow, jr + 3) * xb[3] + ldsv(jrow, jr + 4) * xb[4] +
+               ldsv(jrow, jr + 5) * xb[5];
+        a += sel(same, ldsv(jrow, jr + 6) * t[0] + ldsv(jrow, jr + 7) * t[1] + ldsv(jrow, jr + 8) * t[2], vr(real(0)));
+        a3[r] = a;
+      }
+      A[4 * cc] = sel(has, a3[0] + M.mu * a3[1], vr(real(0)));
+      A[4 * cc + 1] = sel(has, a3[0] - M.mu * a3[1], vr(real(0)));
+      A[4 * cc + 2] = sel(has, a3[0] + M.mu * a3[2], vr(real(0)));
+      A[4 * cc + 3] = sel(has, a3[0] - M.mu * a3[2], vr(real(0)));
+    }
+  };
+#define NM_BUILD4(c0) build_contact(std::integral_constant<int, c0>{}); build_contact(std::integral_constant<int, c0 + 1>{}); \
+                      build_contact(std::integral_constant<int, c0 + 2>{}); build_contact(std::integral_constant<int, c0 + 3>{});
+  NM_BUILD4(0) NM_BUILD4(4)
+#undef NM_BUILD4
+  vr Ajj = u[0] * xb[0] + u[1] * xb[1] + u[2] * xb[2] + u[3] * xb[3] + u[4] * xb[4] + u[5] * xb[5] + (Jl[0] * t[0] + Jl[1] * t[1] + Jl[2] * t[2]);
+  vr ARjj = Ajj + Rr;
+  vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
+
+  nm_stamp(5);
+  // ---- warm start
+  vr jar = jaw - aref;
+  vr f = sel(act & (jar < vr(real(0))), -Dd * jar, vr(real(0)));
+  vr g = bb;
+  for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
+    constexpr int cc = decltype(ccT)::value;
+#pragma unroll
+    for (int r = 0; r < 4; r++) g += A[4 * cc + r] * RDL(f, 4 * cc + r);
+  });
+  {
+    const vr cost = hsum32(sel(act, f * (bb + real(0.5) * (g - bb + Rr * f)), vr(real(0))));
+    const VB worse = cost > vr(real(0));
+    f = sel(worse, vr(real(0)), f);
+    g = sel(worse, bb, g);
+  }
+  // ---- mj_solPGS, each half until ITS tolerance exit
+  const vr hA = real(0.5) * ARjj;
+  V<int> itp = V<int>(0), itn = V<int>(0);
+  {
+    VB run = VB(true);
+    for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
+      vr dcap = vr(real(0)), ccap = vr(real(0));
+      const V<int> lv = opaque_lane() & 31;
+      for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
+        constexpr int cc = decltype(ccT)::value;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int i = 4 * cc + r;
+          vr res = g + Rr * f;
+          vr dl = sel(run, vmax(-res * ARinv, -f), vr(real(0)));
+          vr change = dl * (hA * dl + res);
+          g += A[i] * RDL(dl, i);
+          VB me = lv == i;
+          dcap = sel(me, dl, dcap);
+          ccap = sel(me, change, ccap);
+        }
+      });
+      f = f + dcap;
+      itp = itp + sel(run, V<int>(1), V<int>(0));
+      run = run & !((-hsum32(ccap)) * M.pgs_scale < vr(M.pgs_tol));
+      if (!wany(run)) break;
+    }
+  }
+  nm_stamp(6);
+  // ---- mj_solNoSlip
+  {
+    const V<int> lv = opaque_lane() & 31;
+    const V<int> lvp = lv >> 1;
+    const VB even = (lv & 1) == 0;
+    vr Amq = vr(real(0));
+    for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
+      constexpr int cc = decltype(ccT)::value;
+      Amq = sel(lv == 4 * cc, A[4 * cc + 1], Amq);
+      Amq = sel(lv == 4 * cc + 2, A[4 * cc + 3], Amq);
+    });
+    Amq = sel(even, Amq, shfl_xor1(Amq));
+    const vr K1 = Ajj + shfl_xor1(Ajj) - Amq - Amq;
+    const VB small = K1 < vr(real(1e-15));
+    const vr invK1 = vr(real(1)) / K1, hK1 = real(0.5) * K1;
+    VB run = VB(true);
+    for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
+      vr improvement = vr(real(0));
+      if (iter == 0) improvement = hsum32(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
+      vr dcap = vr(real(0)), ccap = vr(real(0));
+#pragma unroll
+      for (int p = 0; p < kMaxRow2 / 2; p++) {
+        if ((p & 1) == 0 && !(p / 2 < nmax)) break;   // one uniform test per contact (two pairs)
+        {
+          const vr oq = shfl_xor1(f), dg = g - shfl_xor1(g);
+          vr d = vmin(vmax(-dg * invK1, -f), oq);
+          d = sel(small, real(0.5) * (oq - f), d);
+          const vr change = d * (hK1 * d + dg);
+          const VB bad = change > vr(real(1e-10));
+          d = sel(bad | !run, vr(real(0)), d);
+          g += A[2 * p] * RDL(d, 2 * p) + A[2 * p + 1] * RDL(d, 2 * p + 1);
+          const VB me = lvp == p;
+          dcap = sel(me, d, dcap);
+          ccap = sel(me & even & !bad & run, change, ccap);
+        }
+      }
+      f = f + dcap;
+      improvement = improvement - hsum32(ccap);
+      itn = itn + sel(run, V<int>(1), V<int>(0));
+      run = run & !(improvement * M.pgs_scale < vr(M.noslip_tol));
+      if (!wany(run)) break;
+    }
+  }
+  nm_stamp(7);
+  stsv(ibw, hoi + NM_IOFS(it_pgs), itp, hl == 0);
+  stsv(ibw, hoi + NM_IOFS(it_noslip), itn, hl == 0);
+  stsv(rbw, ho + (hl + NM_OFS(efc_f)), f, VB(true));
+  stsv(rbw, ho + (hl + (kMaxRow2 + NM_OFS(efc_f))), vr(real(0)), VB(true));
+  // ---- qfrc_constraint = J' f and the touch sensors
+  vr nf = vr(real(0));
+  VB hit = VB(false);
+  if (last) {
+    nf = f + shfl_xor1(f);
+    nf = nf + shfl_xor2(nf);
+    vr ft[3], fr, sv3[3], Rt[9];
+#pragma unroll
+    for (int j = 0; j < 3; j++) sv3[j] = ldsv(M.footc, Lc * 4 + j);
+    fr = ldsv(M.footc, Lc * 4 + 3);
+#pragma unroll
+    for (int j = 0; j < 9; j++) Rt[j] = SHR(colR, (Lc + 1) * 9 + j);
+    matvec3(ft, Rt, sv3);
+#pragma unroll
+    for (int j = 0; j < 3; j++) ft[j] = ft[j] + SHR(colp, (Lc + 1) * 3 + j);
+    vr dif[3] = {cp[0] - ft[0], cp[1] - ft[1], cp[2] - ft[2]};
+    vr b2 = real(-1) * (nrm[0] * dif[0] + nrm[1] * dif[1] + nrm[2] * dif[2]);
+    vr cq = dif[0] * dif[0] + dif[1] * dif[1] + dif[2] * dif[2] - fr * fr;
+    vr det = b2 * b2 - cq;
+    vr sq = vsqrt(vmax(det, vr(real(0))));
+    hit = !(det < vr(real(1e-15))) & (((-b2 - sq) >= vr(real(0))) | ((-b2 + sq) >= vr(real(0))));
+  }
+#pragma unroll
+  for (int j = 0; j < 6; j++) stsv(rbw, ho + (j + NM_OFS(qfc)), hsum32(Jb[j] * f), hl == 0);
+  {
+    vr s3[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      vr x = Jl[k] * f;
+      x = x + shfl_xor1(x);
+      s3[k] = x + shfl_xor2(x);
+    }
+    const vr tn = sel(act & (nf > vr(real(0))), nf, vr(real(0))), tf = sel(hit, tn, vr(real(0)));
+    const VB lead = act & ((hl & 3) == 0);
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 3; k++) stsv(jrow, jh + (c * 8 + k), s3[k], lead);
+    if (last) { stsv(jrow, jh + (c * 8 + 3), tn, lead); stsv(jrow, jh + (c * 8 + 4), tf, lead); }
+    wave_sync();
+    const VB on = hl < 30;
+    const V<int> lg = sel(on, (hl * 13) >> 6, V<int>(0)), qq = hl - lg * 5;
+    const V<int> c0 = SHI(cstart, lg + 1), cn = SHI(ccnt, lg + 1);
+    vr acc = vr(real(0));
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      VB in = on & (cn > k);
+      acc = acc + sel(in, ldsv(jrow, jh + sel(in, (c0 + k) * 8 + qq, V<int>(0))), vr(real(0)));
+    }
+    stsv(rbw, ho + (lg * 3 + qq + (6 + NM_OFS(qfc))), acc, on & (qq < 3));
+    if (last) {
+      stsv(rbw, ho + (lg + NM_OFS(sens)), acc, on & (qq == 3));          // tibia sites: 10 m spheres see every contact of the body
+      stsv(rbw, ho + (lg + (6 + NM_OFS(sens))), acc, on & (qq == 4));    // foot sites
+      stsv(rbw, ho + V<int>(12 + NM_OFS(sens)), hsum32(sel(act & ((hl & 3) == 0) & (L < 0), tn, vr(real(0)))), hl == 0);
+    }
+  }
+  wave_sync();
+#undef SHR
+#undef SHI
+#undef RDL
+}
+
 // =========================================================================================  stage C beyond kMaxCon contacts
 // Rare: a robot lying on the floor with folded legs can touch it with up to 28 hull vertices, and 15 tibia pairs can collide on
 // top of that; upstream keeps every contact (MuJoCo has no cap), so this path does too. It solves the SAME constraint set with the
@@ -2082,19 +2408,29 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
   nm_stamp(1);
   if (!(ablate & 8)) stage_smooth(w, M, last);
   nm_stamp(2);
+  // collision of every env of the wave, then the constraint stage: both envs in one pass when each has 1..kMaxCon2 floor contacts
+  // (stage_constraint2), else one after the other
   for (int e = 0; e < G; e++) {
     Sh<real>& sh = w.e[e];
-#if defined(NM_ENVCOST) && !defined(NM_EMUL)
-    const unsigned long long t_bc = __builtin_amdgcn_s_memtime();
-#endif
     if (!(ablate & 1)) stage_collide(sh, M, dropped, !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
     if (ablate & 4) { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
-    stage_constraint(sh, w.jrow, M, last, (ablate & 2) != 0);
-#if defined(NM_ENVCOST) && !defined(NM_EMUL)
-    sh.nhop += (int)((__builtin_amdgcn_s_memtime() - t_bc) >> 4);   // measurement build: the hop counter carries this env's B+C cycles / 16
-#endif
-    nm_stamp(8);
   }
+  bool together = false;
+  if constexpr (G == 2) {
+    const int n0 = uniform(w.e[0].ncon), n1 = uniform(w.e[1].ncon);
+    together = n0 >= 1 && n1 >= 1 && n0 <= kMaxCon2 && n1 <= kMaxCon2 && uniform(w.e[0].anypair) == 0 && uniform(w.e[1].anypair) == 0 && !(ablate & 32);
+    if (together) {
+#ifdef NM_EMUL
+      nm_emul_together() += 1;
+#endif
+      stage_constraint2(w, M, last, (ablate & 2) != 0);
+    }
+  }
+  if (!together)
+    for (int e = 0; e < G; e++) {
+      stage_constraint(w.e[e], w.jrow, M, last, (ablate & 2) != 0);
+      nm_stamp(8);
+    }
   stage_integrate(w, M);
   nm_stamp(9);
 }

@@ -39,6 +39,7 @@ def lib():
         L.emu_hull_cache.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
         L.emu_eplen.argtypes = [C.c_void_p]
         L.emu_eplen.restype = C.POINTER(C.c_int64)
+        L.emu_together_count.restype = C.c_long
         _lib = L
     return _lib
 

@@ -135,3 +135,4 @@ void emu_hull_cache(void* h, int set, int* hc) { ((EmuBase*)h)->hull_cache(set, 
 int emu_nrew() { return nm::kNREW; }
 int emu_dbg_n() { return nm::kDbgN; }
 }
+extern "C" long emu_together_count() { return nm::nm_emul_together(); }
