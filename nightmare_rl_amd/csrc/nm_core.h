@@ -2424,6 +2424,7 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
       nm_emul_together() += 1;
 #endif
       stage_constraint2(w, M, last, (ablate & 2) != 0);
+      nm_stamp(8);
     }
   }
   if (!together)
