@@ -1062,11 +1062,14 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       }
       if (full) {
         NM_BSTAMP(12);
+        const int held = si;                    // the vertex whose ring the lanes hold
         si = support_exhaustive(M, ld, nvert, vadr);
         sh.hcache[7] += 1;
-        hull_ring(M, vadr + si, si, nb[g], vv[g]);
-        val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
-        sv[g] = rdlane(val[g], kSelfLane);
+        if (si != held) {                       // a tie fallback usually confirms the vertex it started from: no second dependent gather then
+          hull_ring(M, vadr + si, si, nb[g], vv[g]);
+          val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
+          sv[g] = rdlane(val[g], kSelfLane);
+        }
         NM_BSTAMP(15);
       }
       if (si != cur[g]) sh.hcache[g] = si;
@@ -2390,18 +2393,42 @@ template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) 
 // mj_step(model, data, 1) for the G envs of the wave
 template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<real>& M, bool last, int* dropped, int ablate) {
   const V<int> lane = opaque_lane();
-  for (int e = 0; e < G; e++) {
-    Sh<real>& sh = w.e[e];
+  if constexpr (G == 2) {   // both envs at once on half-waves (lanes 0..31 | 32..63), as in env_load2
+    constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real));
+    real* rbw = reinterpret_cast<real*>(&w.e[0]);
+    const V<int> hl = lane & 31, ho = (lane >> 5) * kSR;
     {  // mj_checkPos / mj_checkVel
-      VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
-               (visbad(ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0)))) & (lane < kNV));
-      if (wany(bad)) { sh.nwarn += 1; reset_data(sh, M); }
+      const VB bad = (visbad(ldsv(rbw, ho + (sel(hl < kNQ, hl, V<int>(0)) + NM_OFS(qpos)))) & (hl < kNQ)) |
+                     (visbad(ldsv(rbw, ho + (sel(hl < kNV, hl, V<int>(0)) + NM_OFS(qvel)))) & (hl < kNV));
+      const uint64_t bm = ballot(bad);
+      if (bm) {
+#pragma unroll
+        for (int e = 0; e < 2; e++)
+          if ((bm >> (32 * e)) & 0xffffffffull) { w.e[e].nwarn += 1; reset_data(w.e[e], M); }
+      }
     }
-    {  // mj_kinematics normalises the free joint's quaternion in qpos
-      real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
-      real a = sh.qpos[3] / n, b = sh.qpos[4] / n, c = sh.qpos[5] / n, d = sh.qpos[6] / n;
+    {  // mj_kinematics normalises the free joint's quaternion in qpos: lanes 3..6 of each half hold the four components
+      const V<real> q3 = ldsv(rbw, ho + (3 + NM_OFS(qpos))), q4 = ldsv(rbw, ho + (4 + NM_OFS(qpos))), q5 = ldsv(rbw, ho + (5 + NM_OFS(qpos))),
+                    q6 = ldsv(rbw, ho + (6 + NM_OFS(qpos)));
+      const V<real> n = vsqrt(q3 * q3 + q4 * q4 + q5 * q5 + q6 * q6);
+      const V<real> mine = sel(hl == 3, q3, sel(hl == 4, q4, sel(hl == 5, q5, q6)));
       wave_sync();
-      sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
+      stsv(rbw, ho + (hl + NM_OFS(qpos)), mine / n, (hl >= 3) & (hl <= 6));
+    }
+  } else {
+    for (int e = 0; e < G; e++) {
+      Sh<real>& sh = w.e[e];
+      {  // mj_checkPos / mj_checkVel
+        VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
+                 (visbad(ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0)))) & (lane < kNV));
+        if (wany(bad)) { sh.nwarn += 1; reset_data(sh, M); }
+      }
+      {  // mj_kinematics normalises the free joint's quaternion in qpos
+        real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
+        real a = sh.qpos[3] / n, b = sh.qpos[4] / n, c = sh.qpos[5] / n, d = sh.qpos[6] / n;
+        wave_sync();
+        sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
+      }
     }
   }
   wave_sync();
