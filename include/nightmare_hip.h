@@ -177,6 +177,12 @@ int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_
                      const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* target_values,
                      int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
                      int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
+/* 1 if the network runs on the compiled register-resident kernels (the reference's 66 -> 54 -> 42 -> 30 -> 18 | 1 shape), else 0 */
+int32_t nm_ppo_has_fast_path(const nm_ppo* h);
+/* rsl_rl v1.0.2 PPO.act (caller reference train.py:54) in ONE launch, fast-path networks only: merged actor+critic forward from the
+ * update's packed weights (always current: no repack between update and collection), then exactly what nm_ppo_sample does */
+int nm_ppo_act(nm_ppo* h, const float* flat_dev, const float* obs_dev, int32_t N, uint64_t seed, const int64_t* iter_dev, int32_t step,
+               float* actions_dev, float* logp_dev, float* values_dev, float* mu_dev, float* sigma_dev, float* obs_store_dev, void* stream);
 /* gradient of the last mini-batch in flat order followed by the mini-batch's mean KL to the behaviour policy, [num_params + 1] floats:
  * direction 0 copies them to grad_dev, 1 replaces them by grad_dev */
 int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream);

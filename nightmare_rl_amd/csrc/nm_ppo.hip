@@ -657,6 +657,130 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
   }
   PPO_STAMP(14);
 }
+
+// ------------------------------------------------------------------------------------------------ collection step on the same packing
+// PPO.act for the reference-shaped network in ONE launch: the register-resident forward of k_ppo_fwdbwd_fast (one wave = 16 rows,
+// weights from the update's own packed copy - no separate repack for the collector), then the sampling head on the output registers:
+// lane (row r, q) holds outputs 16 t + 4 q + reg, i.e. whole action pairs, so Box-Muller pairs, log-probability partials and the
+// storage writes need no exchange; the log-probability crosses the four q lanes with two shuffles. Same counter generator and keys
+// as nm_ppo_sample (seed, iteration, step, env, action pair).
+__device__ __forceinline__ float ppo_u24(uint64_t seed, uint64_t a, uint64_t b) {   // = u24 of nm_rl.hip
+  uint64_t x = seed + 0x9E3779B97F4A7C15ull * (a + 1) + 0xD1B54A32D192ED03ull * b;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return ((float)(uint32_t)(x >> 40) + 1.0f) * (1.0f / 16777216.0f);
+}
+template <class S>
+__global__ void __launch_bounds__(64) k_ppo_act_fast(PpoNet net, const float* __restrict__ obs, const float* __restrict__ std, int N, uint64_t seed,
+                                                     const int64_t* __restrict__ iter_dev, int step, float* __restrict__ actions, float* __restrict__ logp,
+                                                     float* __restrict__ values, float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ obs_store) {
+  typedef Seq<S> Q;
+  constexpr int NL = S::NL, MT = S::maxT(), PO = S::P(NL) / 16, AO = S::aout(NL - 1), I = S::Kr(0), T0 = S::P(0) / 16, NF = Q::count(true);
+  static_assert(AO % 2 == 0, "action pairs");
+  const int lane = threadIdx.x, r = lane & 15, q = lane >> 4;
+  const int row = blockIdx.x * 16 + r;
+  const bool live = row < N;
+  const size_t lrow = live ? row : 0;
+  auto wfrag = [&](auto IDX) -> f32x4 {
+    constexpr int e = Q::entry(true, IDX), l = e & 15, to = (e >> 4) & 15, tk = e >> 8;
+    return net.pf[l][(to * (S::P(l) / 16) + tk) * 64 + lane];
+  };
+  f32x4 ring[kRing];
+  f32x4 a[NL][MT], out[PO];
+  sfor<T0>([&](auto T) {
+    constexpr int t = T;
+    f32x4 v;
+    if constexpr (16 * t + 16 <= I) {
+      v = *reinterpret_cast<const f32x4u*>(obs + lrow * I + 16 * t + 4 * q);
+      if (obs_store && live) *reinterpret_cast<f32x4u*>(obs_store + lrow * I + 16 * t + 4 * q) = v;
+    } else {
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) {
+        const int f = 16 * t + 4 * q + reg;
+        const float x = obs[lrow * I + (f < I ? f : 0)];
+        if (obs_store && live && f < I) obs_store[lrow * I + f] = x;
+        v[reg] = f < I ? x : (f == I ? 1.0f : 0.0f);
+      }
+    }
+    a[0][t] = v;
+  });
+  sfor<kRing>([&](auto i) { ring[i] = wfrag(i); });
+  sfor<NL>([&](auto L) {
+    constexpr int l = L, nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
+    constexpr bool last = l == NL - 1;
+    sfor<(nto + 1) / 2>([&](auto PP) {
+      constexpr int to0 = 2 * PP, to1 = to0 + 1;
+      f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+      sfor<nkt>([&](auto TK) {
+        constexpr int tk = TK;
+        constexpr bool z0 = S::nz(l, to0, tk), z1 = to1 < nto && S::nz(l, to1, tk);
+        f32x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+        if constexpr (z0) {
+          constexpr int i = Q::index(true, l, to0, tk);
+          w0 = ring[i % kRing];
+          if constexpr (i + kRing < NF) ring[i % kRing] = wfrag(std::integral_constant<int, (i + kRing < NF ? i + kRing : 0)>{});
+        }
+        if constexpr (z1) {
+          constexpr int i = Q::index(true, l, to1, tk);
+          w1 = ring[i % kRing];
+          if constexpr (i + kRing < NF) ring[i % kRing] = wfrag(std::integral_constant<int, (i + kRing < NF ? i + kRing : 0)>{});
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          if constexpr (z0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[l][tk][j], acc0, 0, 0, 0);
+          if constexpr (z1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[l][tk][j], acc1, 0, 0, 0);
+        }
+      });
+      auto finish = [&](auto TO, const f32x4& acc) {
+        constexpr int to = TO;
+        if constexpr (last) {
+          out[to] = acc;
+        } else {
+#pragma unroll
+          for (int reg = 0; reg < 4; reg++) {
+            const int col = 16 * to + 4 * q + reg;
+            const float v = acc[reg];
+            a[l + 1][to][reg] = col < S::Or(l) ? (v > 0.0f ? v : __expf(v) - 1.0f) : (col == S::Or(l) ? 1.0f : 0.0f);
+          }
+        }
+      };
+      finish(std::integral_constant<int, to0>{}, acc0);
+      if constexpr (to1 < nto) finish(std::integral_constant<int, to1>{}, acc1);
+    });
+  });
+  // ---- sampling head
+  const uint64_t ctr = (uint64_t)iter_dev[0] * 4096ull + (uint64_t)step;
+  float lp = 0.0f;
+  sfor<PO>([&](auto T) {
+    constexpr int t = T;
+#pragma unroll
+    for (int pr = 0; pr < 2; pr++) {
+      const int f0 = 16 * t + 4 * q + 2 * pr;            // even action index: the pair (f0, f0 + 1) shares one Box-Muller draw
+      if (f0 < AO) {
+        const float u1 = ppo_u24(seed, (uint64_t)lrow * 64 + f0, ctr), u2 = ppo_u24(seed, (uint64_t)lrow * 64 + f0 + 1, ctr);
+        const float rad = sqrtf(-2.0f * __logf(u1));
+        float sn, cs;
+        __sincosf(6.283185307179586f * u2, &sn, &cs);
+        const float z[2] = {rad * cs, rad * sn};
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++) {
+          const float m = out[t][2 * pr + hh], sd = std[f0 + hh];
+          if (live) {
+            actions[lrow * AO + f0 + hh] = m + sd * z[hh];
+            mu[lrow * AO + f0 + hh] = m;
+            sigma[lrow * AO + f0 + hh] = sd;
+          }
+          lp += -0.5f * z[hh] * z[hh] - __logf(sd) - 0.9189385332046727f;
+        }
+      } else if (f0 == AO && live) {
+        values[lrow] = out[t][2 * pr];
+      }
+    }
+  });
+  lp += __shfl_xor(lp, 16); lp += __shfl_xor(lp, 32);
+  if (q == 0 && live) logp[lrow] = lp;
+}
 // the reference's networks (envs/nightmare_v3_config.py:107-109): 66 -> 54 -> 42 -> 30 -> 18 | 1
 typedef Shape4<66, 54, 42, 30, 18, 54, 42, 30> RefShape;
 
@@ -948,6 +1072,20 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
     if (ppo_pack(h, s)) return 1;
   }
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_minibatch: launch failed");
+  return 0;
+}
+// does this network run on the compiled fast kernels (k_ppo_fwdbwd_fast, k_ppo_act_fast)?
+extern "C" int32_t nm_ppo_has_fast_path(const nm_ppo* h) { return h && h->fast ? 1 : 0; }
+// PPO.act in one launch (fast-path networks only): forward of the merged network from the update's packed weights, sampling,
+// log-probability, value, and the rollout-storage writes of nm_ppo_sample (same generator and keys)
+extern "C" int nm_ppo_act(nm_ppo* h, const float* flat_dev, const float* obs, int32_t N, uint64_t seed, const int64_t* iter_dev, int32_t step,
+                          float* actions, float* logp, float* values, float* mu, float* sigma, float* obs_store, void* stream) {
+  if (!h || !flat_dev || !obs || !iter_dev || !actions || !logp || !values || !mu || !sigma || N <= 0) return nm_policy_set_error("nm_ppo_act: bad argument");
+  if (!h->fast) return nm_policy_set_error("nm_ppo_act: this network shape has no compiled fast path (use nm_policy_forward + nm_ppo_sample)");
+  PPO_CHK(hipSetDevice(h->device));
+  hipLaunchKernelGGL(k_ppo_act_fast<RefShape>, dim3((N + 15) / 16), dim3(64), 0, (hipStream_t)stream, h->net, obs, flat_dev + (h->nparam - h->A), N, seed, iter_dev,
+                     step, actions, logp, values, mu, sigma, obs_store);
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_act: launch failed");
   return 0;
 }
 // gradient of the last mini-batch in flat order followed by its mean KL, nparam + 1 floats: direction 0 copies them into grad_dev,

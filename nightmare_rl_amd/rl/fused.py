@@ -25,8 +25,11 @@ class FusedCollector:
             return False
         return all(x.out_features + y.out_features <= 256 for x, y in zip(a, c)) and a[0].in_features <= 256
 
-    def __init__(self, ac, num_envs, device, seed=0):
+    def __init__(self, ac, num_envs, device, seed=0, update=None):
+        """update: the FusedUpdate of the same networks, if there is one. When its handle has the compiled fast path, `act` is ONE
+        launch (nm_ppo_act: forward from the update's own packed weights + sampling) and `refresh` has nothing to repack."""
         self.ac, self.device, self.N = ac, torch.device(device), int(num_envs)
+        self.update = update if (update is not None and update.has_fast_path) else None
         self.a_lin = [m for m in ac.actor if isinstance(m, nn.Linear)]
         self.c_lin = [m for m in ac.critic if isinstance(m, nn.Linear)]
         self.A = self.a_lin[-1].out_features
@@ -42,11 +45,12 @@ class FusedCollector:
     def refresh(self, iteration):
         """Merge the current actor / critic parameters into the packed network and set the iteration the action noise is keyed by.
         Call once per learning iteration, outside graph capture."""
-        ws, bs = [], []
-        for l, (x, y) in enumerate(zip(self.a_lin, self.c_lin)):
-            ws.append(torch.cat([x.weight, y.weight], 0) if l == 0 else torch.block_diag(x.weight, y.weight))
-            bs.append(torch.cat([x.bias, y.bias], 0))
-        self.net.load(ws, bs)
+        if self.update is None:
+            ws, bs = [], []
+            for l, (x, y) in enumerate(zip(self.a_lin, self.c_lin)):
+                ws.append(torch.cat([x.weight, y.weight], 0) if l == 0 else torch.block_diag(x.weight, y.weight))
+                bs.append(torch.cat([x.bias, y.bias], 0))
+            self.net.load(ws, bs)
         self.std = self.ac.std.detach().contiguous()
         self.iter_dev.fill_(int(iteration))
 
@@ -56,6 +60,12 @@ class FusedCollector:
         if s >= storage.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
         obs = obs if (obs.dtype == torch.float32 and obs.is_contiguous()) else obs.contiguous().float()
+        if self.update is not None:
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self._L.nm_ppo_act(self.update._h, self.update.flat.data_ptr(), obs.data_ptr(), self.N, self.seed, self.iter_dev.data_ptr(), s,
+                                          storage.actions[s].data_ptr(), storage.actions_log_prob[s].data_ptr(), storage.values[s].data_ptr(),
+                                          storage.mu[s].data_ptr(), storage.sigma[s].data_ptr(), storage.observations[s].data_ptr(), stream))
+            return storage.actions[s]
         self.net.forward(obs, out=self.out)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._L.nm_ppo_sample(self.out.data_ptr(), self.std.data_ptr(), obs.data_ptr(), self.N, self.A, obs.shape[1], self.seed,
@@ -115,6 +125,7 @@ class FusedUpdate:
         self._h = h
         assert self._L.nm_ppo_num_params(h) == n
         self.A, self.n_obs = a[-1].out_features, a[0].in_features
+        self.has_fast_path = bool(self._L.nm_ppo_has_fast_path(h))
         self.step_count = 0
         self._bind_optimizer_state()
         self.sync(lr)

@@ -38,7 +38,7 @@ class PPO:
             if FusedUpdate.supported(self.actor_critic, self.device):
                 self.fused_update = FusedUpdate(self.actor_critic, self.optimizer, self.device, self.learning_rate)
             rank = dist.get_rank() if _world() > 1 else 0     # every rank draws its own action noise
-            self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=(torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF)
+            self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=(torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF, update=self.fused_update)
 
     def after_load(self):
         """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow."""
