@@ -107,7 +107,8 @@ template <class real> struct Args {
   real* dbg;             // optional [N][kDbgN]
   int nsub;              // decimation
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
-  int ablate;            // measurement only: bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage
+  int ablate;            // measurement only: bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage, bit4 no tibia pairs,
+                         // bit5 constraint stage one env at a time, bit7 no env epilogue (E3-E8), bit8 no observation
   // observation noise (env.py:109-119,304-305): null = off
   const real* noise_vec; // [66] noise_scale_vec
   const real* noise_u;   // [N,66] injected uniforms (parity tests) or null = counter RNG
@@ -2948,6 +2949,7 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
 #endif
   }
   if (A.physics_only) return;
+  if (A.ablate & 128) return;   // measurement only: epilogue inputs were loaded, nothing of E3-E8 runs
   NM_ESTAMP(11);
 
   // ---- E3 (env.py:212-232): frame transforms with the POST-integration quaternion, stale cvel/sensors
@@ -3119,7 +3121,7 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
   }
   NM_ESTAMP(14);
   // ---- E8 (env.py:291-311): observation (66), clipped, float32
-  {
+  if (!(A.ablate & 256)) {
     vr head[12] = {blv[0] * M.obs_lin, blv[1] * M.obs_lin, blv[2] * M.obs_lin, bav[0] * M.obs_ang, bav[1] * M.obs_ang, bav[2] * M.obs_ang,
                    pg[0], pg[1], pg[2], cmd[0] * M.obs_lin, cmd[1] * M.obs_lin, cmd[2] * M.obs_ang};
     vr o = vr(real(0));
