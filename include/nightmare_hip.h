@@ -98,7 +98,7 @@ int nm_set_feet_state(nm_env* env, const double* feet_air_time, const unsigned c
 /* RNG-free command resampling for parity tests: HOST [N,4] uniforms in [0,1) used by the next steps instead
  * of the counter RNG ((x,yaw) for the periodic resample :235, (x,yaw) for the reset resample :356). NULL = RNG. */
 int nm_set_command_uniforms(nm_env* env, const double* u_host);
-/* counters: [0] contacts dropped by the per-env contact cap, [1] MuJoCo-style bad-state resets,
+/* counters: [0] contacts dropped (always 0 since every contact is kept: the matrix-free solver takes what the register-resident one cannot), [1] MuJoCo-style bad-state resets,
  * [2] support-vertex searches that fell back from the warm start to the exhaustive scan */
 int nm_get_counters(nm_env* env, int64_t* out3);
 /* optional debug dump [N,256] reals (dtype of the env) written by nm_step; NULL disables */

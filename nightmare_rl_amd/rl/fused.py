@@ -1,10 +1,14 @@
 """Rollout collection on hand-written kernels: what rsl_rl v1.0.2's `PPO.act` + `PPO.process_env_step` do per step (actor mean,
 critic value, Normal sample, log-probability, transition record, time-out bootstrap, episode bookkeeping; caller reference
-train.py:54) in THREE launches - the fused actor+critic forward on the matrix cores (one merged network: the two MLPs side by side,
-block-diagonal hidden layers), `nm_ppo_sample` and `nm_ppo_record` - writing straight into the rollout storage.
+train.py:54), writing straight into the rollout storage:
+  * networks of the reference's shape, next to a FusedUpdate: TWO launches per step - `nm_ppo_act` (register-resident forward of the
+    merged actor+critic network from the update's own packed weights + sampling head) and `nm_ppo_record`;
+  * other qualifying networks: THREE - the fused actor+critic forward on the matrix cores (`nm_policy_forward` on one merged network:
+    the two MLPs side by side, block-diagonal hidden layers), `nm_ppo_sample`, `nm_ppo_record`; the packed copy of the parameters is
+    refreshed once per iteration by `refresh()`, outside any captured graph.
 
 Used by PPO when the networks qualify (`FusedCollector.supported`); otherwise PPO keeps its torch path (host tests, other
-activations). The packed copy of the parameters is refreshed once per iteration by `refresh()`, outside any captured graph."""
+activations)."""
 import ctypes as C
 
 import torch
