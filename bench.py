@@ -27,41 +27,49 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
 def host_cores():
-    """CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (a GPU box gives a share of a big host)."""
-    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    """(threads the CPU leg will use, CPUs visible to this process). Threads = the affinity mask, capped by the cgroup CPU quota when
+    one is visible; on a host with more than 64 visible CPUs and no visible quota (a GPU box is a share of a big host) the leg stays
+    within the 16-CPU share documented for one GPU. `cores` in the JSON line is the number of OpenMP threads actually used."""
+    vis = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = vis
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
             n = min(n, max(1, int(float(quota) / float(period))))
     except Exception:
         pass
-    return max(1, min(n, 16)) if n > 64 else n   # no quota visible on a >64-thread host: stay within the documented 16-CPU share
+    return (max(1, min(n, 16)) if n > 64 else n), vis
 
 
-def _time_oracle(n, threads, seconds):
+def _time_oracle(n, threads, seconds, physics_only=False):
     from oracle import oracle as orc
     env = orc.OracleEnv(n, seed=0, num_threads=threads)
     env.reset()
     rng = np.random.default_rng(0)
     acts = [rng.uniform(-1, 1, (n, 18)).astype(np.float32) for _ in range(8)]
+    step = env.step_physics if physics_only else env.step
     for i in range(3):
-        env.step(acts[i % 8])
+        step(acts[i % 8])
     t0 = time.perf_counter()
     k = 0
     while time.perf_counter() - t0 < seconds:
-        env.step(acts[k % 8])
+        step(acts[k % 8])
         k += 1
     return n * k / (time.perf_counter() - t0), k
 
 
 def cpu_baseline(envs=4096):
     """The CPU oracle (a port: MuJoCo itself is not installable) on this box's host cores: the same workload (N envs, random
-    actions, full step()) on a bounded sample, plus the grid SURVEY 8(d) asks for - N in {1, N} x T in {1, all cores}. It is a C
-    restatement with no Python in the loop, i.e. an upper bound for the reference's own MuJoCo + numpy path. ~20 s in total."""
-    cores = host_cores()
+    actions, full step()) on a bounded sample, plus the grid SURVEY 8(d) / BASELINE.md ask for - N in {1, N} x T in {1, all cores},
+    with the env epilogue (obs / reward / reset: what `value` is) and without it (mj_step x decimation only, the shape of the
+    reference's simple_test.py:25-45). It is a C restatement with no Python in the loop, i.e. an upper bound for the reference's own
+    MuJoCo + numpy path. ~25 s in total."""
+    cores, visible = host_cores()
     v_all, k = _time_oracle(envs, cores, 10.0)
-    grid = {f"N{envs}_T{cores}": v_all, "N1_T1": _time_oracle(1, 1, 3.0)[0], f"N{envs}_T1": _time_oracle(envs, 1, 5.0)[0]}
-    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    grid = {f"N{envs}_T{cores}": v_all, "N1_T1": _time_oracle(1, 1, 3.0)[0], f"N{envs}_T1": _time_oracle(envs, 1, 4.0)[0],
+            f"N{envs}_T{cores}_physics_only": _time_oracle(envs, cores, 4.0, True)[0], "N1_T1_physics_only": _time_oracle(1, 1, 2.0, True)[0],
+            f"N{envs}_T1_physics_only": _time_oracle(envs, 1, 3.0, True)[0]}
+    return {"value": v_all, "unit": "env-steps/s", "cores": cores, "host_cpus_visible": visible, "kind": "port",
             "sample": f"{envs} envs x {k} random-action steps from reset (fp64 C restatement of mj_step + env epilogue, OpenMP over envs)",
             "grid_env_steps_per_s": grid}
 
@@ -121,15 +129,17 @@ def main():
     horizon = 80
 
     ncoll = 0
+    mism = torch.zeros((), dtype=torch.int64, device=dev)      # gathered[rank*E:(rank+1)*E] != what this rank contributed (device-side count)
 
     def one_step(i, last=False):
-        nonlocal returns, gathered, ncoll
+        nonlocal returns, gathered, ncoll, mism
         _, _, rew, done, _ = env.step(acts[i % pool])
         returns += rew
         # PPO-update boundary: one all-gather of per-env returns over xGMI, every `horizon` steps and at the end of the run (so a
         # short timed region still contains the collective)
         if ((i + 1) % horizon == 0 or last) and world > 1:
             gathered = gather_returns(returns, total_envs=world * E)
+            mism += (gathered[rank * E:(rank + 1) * E] != returns).sum()     # ordered by global env id: no host synchronisation here
             returns.zero_()
             ncoll += 1
 
@@ -151,21 +161,25 @@ def main():
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
+    if world > 1:
+        dist.all_reduce(mism)
 
     out = None
     if rank == 0:
         value = world * E * args.steps / dt
         # roofline leg: HIP events around the dominant (step) kernel on its launch stream, separate pass
         env.profile(True)
-        for i in range(min(args.steps, 300)):
-            env.step(acts[i % pool])
+        for i in range(max(300, min(args.steps, 1000))):     # >= 300 back-to-back launches whatever --steps is: on a near-idle queue
+            env.step(acts[i % pool])                          # the event pair itself inflates a 75 us kernel by several us
         k_ms, k_n = env.profile(False)
         k_avg = k_ms / max(k_n, 1) * 1e-3
         achieved = B_FULL * E / k_avg / 1e9
         # HBM-side bytes per launch and VALU issue utilisation are NOT measured by this process: they come from the committed
         # rocprofv3 --pmc passes of this same command (separate runs, as the counter guide prescribes); null when there are none
         traffic = valu = None
-        pmc_file = os.path.join("profiles", "r02_pmc_step_kernel.json")
+        import glob
+        cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_step_kernel.json")))     # the newest round's counters
+        pmc_file = os.path.relpath(cands[-1], ROOT) if cands else None
         try:
             tj = json.load(open(os.path.join(ROOT, pmc_file)))
             traffic = tj["hbm_bytes_per_launch"] * (E / 4096.0)
@@ -223,7 +237,7 @@ def main():
                                    "(18-DoF dynamics + floor contact, PGS x3 + noslip x4) + obs/reward/termination/reset",
                        "envs_per_gpu": E, "decimation": 2,
                        "sharding": f"dp{world} by env id, all-gather of returns every {horizon} steps and on the last timed step"},
-            "collectives_timed": ncoll,
+            "collectives_timed": ncoll, "gather_order_mismatches": int(mism.item()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_file and f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)",
                          "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6,

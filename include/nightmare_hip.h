@@ -121,9 +121,8 @@ int nm_get_state_record(nm_env* env, double* qpos, double* qvel, int32_t* bad_st
  * kernel with HIP events on the launch stream. Each call synchronises, returns the summed kernel time and the
  * launch count since the previous call, clears them, and sets the new enable state. */
 int nm_profile(nm_env* env, int32_t enable, double* sum_ms, int64_t* count);
-/* Measurement only (results become wrong): skip kernel stages to attribute time. bit0 collision, bit1 solver sweeps,
- * bit2 whole constraint stage, bit3 smooth-dynamics stage. 0 = normal. */
-int nm_set_ablation(nm_env* env, int32_t mask);
+/* Stage-skipping measurement switches are NOT part of this ABI: they exist only in the -DNM_MEASURE build
+ * (libnightmare_hip_measure.so, include/nightmare_hip_measure.h). */
 
 /* ---- ActorCritic MLP forward on the matrix cores (rsl_rl v1.0.2 ActorCritic: Linear -> ELU x n_hidden -> Linear; reference call
  * sites play.py:122 `nn.act(obs)`, train.py:40), batched over envs, exact-f32 MFMA, all layers in one launch.

@@ -10,7 +10,7 @@ DTYPE_F32, DTYPE_F64 = 0, 1
 
 EXPORTS = ["nm_default_config", "nm_reward_name", "nm_last_error", "nm_create", "nm_destroy", "nm_num_envs", "nm_dtype", "nm_reset",
            "nm_step", "nm_step_physics", "nm_get_state", "nm_set_state", "nm_get_buffers", "nm_set_buffers",
-           "nm_set_command_uniforms", "nm_get_feet_state", "nm_set_feet_state", "nm_get_counters", "nm_set_debug_buffer", "nm_policy_create", "nm_policy_destroy", "nm_policy_load", "nm_policy_forward", "nm_profile", "nm_set_ablation", "nm_gae", "nm_ppo_sample", "nm_ppo_record", "nm_ppo_create", "nm_ppo_destroy", "nm_ppo_num_params", "nm_ppo_sync_params", "nm_ppo_minibatch", "nm_ppo_copy_grad", "nm_ppo_get_state", "nm_ppo_has_fast_path", "nm_ppo_act",
+           "nm_set_command_uniforms", "nm_get_feet_state", "nm_set_feet_state", "nm_get_counters", "nm_set_debug_buffer", "nm_policy_create", "nm_policy_destroy", "nm_policy_load", "nm_policy_forward", "nm_profile", "nm_gae", "nm_ppo_sample", "nm_ppo_record", "nm_ppo_create", "nm_ppo_destroy", "nm_ppo_num_params", "nm_ppo_sync_params", "nm_ppo_minibatch", "nm_ppo_copy_grad", "nm_ppo_get_state", "nm_ppo_has_fast_path", "nm_ppo_act",
            "nm_set_observation_noise", "nm_set_noise_uniforms", "nm_set_state_record", "nm_get_state_record",
            "nm_nik_create", "nm_nik_destroy", "nm_nik_reset", "nm_nik_set_gait", "nm_nik_update", "nm_nik_get_state"]
 
@@ -30,6 +30,8 @@ class NightmareHipError(RuntimeError):
 
 
 _lib = None
+_measure = None
+MEASURE_LIB_PATH = os.path.join(HERE, "csrc", "libnightmare_hip_measure.so")
 
 
 def load():
@@ -40,7 +42,23 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NightmareHipError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                                 "There is no CPU fallback.")
-    L = C.CDLL(LIB_PATH)
+    _lib = _bind(C.CDLL(LIB_PATH), full=True)
+    return _lib
+
+
+def load_measure():
+    """The -DNM_MEASURE build of the env entry points (include/nightmare_hip_measure.h): stage-skipping switches for scripts/ and
+    for the device bit-equality test. Never used by the product path; pass it as NightmareV3Env(..., lib=load_measure())."""
+    global _measure
+    if _measure is None:
+        if not os.path.exists(MEASURE_LIB_PATH):
+            raise NightmareHipError(f"{MEASURE_LIB_PATH} not found: make -C nightmare_rl_amd/csrc measure")
+        _measure = _bind(C.CDLL(MEASURE_LIB_PATH), full=False)
+        _measure.nm_set_ablation.argtypes = [C.c_void_p, C.c_int32]
+    return _measure
+
+
+def _bind(L, full):
     vp = C.c_void_p
     L.nm_default_config.argtypes = [C.POINTER(NmConfig)]
     L.nm_default_config.restype = None
@@ -64,7 +82,12 @@ def load():
     L.nm_get_counters.argtypes = [vp, vp]
     L.nm_set_debug_buffer.argtypes = [vp, vp]
     L.nm_profile.argtypes = [vp, C.c_int32, vp, vp]
-    L.nm_set_ablation.argtypes = [vp, C.c_int32]
+    L.nm_set_observation_noise.argtypes = [vp, vp]
+    L.nm_set_noise_uniforms.argtypes = [vp, vp]
+    L.nm_set_state_record.argtypes = [vp, C.c_int32]
+    L.nm_get_state_record.argtypes = [vp, vp, vp, vp]
+    if not full:        # the measurement build holds the env entry points only
+        return L
     L.nm_gae.argtypes = [vp, vp, vp, vp, C.c_int32, C.c_int32, C.c_float, C.c_float, vp, vp]
     L.nm_ppo_sample.argtypes = [vp, vp, vp, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.nm_ppo_record.argtypes = [vp, vp, vp, vp, C.c_float, C.c_int32, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp, vp]
@@ -82,10 +105,6 @@ def load():
     L.nm_policy_destroy.argtypes = [vp]
     L.nm_policy_load.argtypes = [vp, vp, vp, vp]
     L.nm_policy_forward.argtypes = [vp, vp, C.c_int32, vp, vp]
-    L.nm_set_observation_noise.argtypes = [vp, vp]
-    L.nm_set_noise_uniforms.argtypes = [vp, vp]
-    L.nm_set_state_record.argtypes = [vp, C.c_int32]
-    L.nm_get_state_record.argtypes = [vp, vp, vp, vp]
     L.nm_nik_create.argtypes = [C.c_int32, C.c_int32]
     L.nm_nik_create.restype = vp
     L.nm_nik_destroy.argtypes = [vp]
@@ -94,13 +113,12 @@ def load():
     L.nm_nik_set_gait.argtypes = [vp, vp, C.c_int32, C.c_int32, vp]
     L.nm_nik_update.argtypes = [vp, vp, vp, vp, vp, C.c_double, C.c_double, vp, vp, vp]
     L.nm_nik_get_state.argtypes = [vp, vp, vp, vp]
-    _lib = L
     return L
 
 
-def check(rc):
+def check(rc, L=None):
     if rc != 0:
-        raise NightmareHipError(load().nm_last_error().decode())
+        raise NightmareHipError((L or load()).nm_last_error().decode())
 
 
 def reward_names():

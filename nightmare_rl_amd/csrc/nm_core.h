@@ -27,6 +27,13 @@
 
 #include "simt.h"
 
+// Stage-skipping switches exist only in measurement builds (make measure: -DNM_MEASURE, libnightmare_hip_measure.so); in the shipped
+// library the mask is the constant 0 and every branch on it is compiled away.
+#ifdef NM_MEASURE
+#define NM_ABLATE(mask) (mask)
+#else
+#define NM_ABLATE(mask) 0
+#endif
 namespace nm {
 using namespace simt;
 
@@ -107,7 +114,7 @@ template <class real> struct Args {
   real* dbg;             // optional [N][kDbgN]
   int nsub;              // decimation
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
-  int ablate;            // measurement only: bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage, bit4 no tibia pairs,
+  int ablate;            // read only by -DNM_MEASURE builds (the shipped library has no way to set it and compiles the tests away): bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage, bit4 no tibia pairs,
                          // bit5 constraint stage one env at a time, bit7 no env epilogue (E3-E8), bit8 no observation
   // observation noise (env.py:109-119,304-305): null = off
   const real* noise_vec; // [66] noise_scale_vec
@@ -2949,7 +2956,7 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
 #endif
   }
   if (A.physics_only) return;
-  if (A.ablate & 128) return;   // measurement only: epilogue inputs were loaded, nothing of E3-E8 runs
+  if (NM_ABLATE(A.ablate) & 128) return;   // measurement only: epilogue inputs were loaded, nothing of E3-E8 runs
   NM_ESTAMP(11);
 
   // ---- E3 (env.py:212-232): frame transforms with the POST-integration quaternion, stale cvel/sensors
@@ -3121,7 +3128,7 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
   }
   NM_ESTAMP(14);
   // ---- E8 (env.py:291-311): observation (66), clipped, float32
-  if (!(A.ablate & 256)) {
+  if (!(NM_ABLATE(A.ablate) & 256)) {
     vr head[12] = {blv[0] * M.obs_lin, blv[1] * M.obs_lin, blv[2] * M.obs_lin, bav[0] * M.obs_ang, bav[1] * M.obs_ang, bav[2] * M.obs_ang,
                    pg[0], pg[1], pg[2], cmd[0] * M.obs_lin, cmd[1] * M.obs_lin, cmd[2] * M.obs_ang};
     vr o = vr(real(0));
@@ -3197,7 +3204,7 @@ template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<r
   }
   nm_stamp(0);
   int dropped = 0;
-  for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, A.ablate);
+  for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, NM_ABLATE(A.ablate));
   if constexpr (G == 2) {
     env_finish2(w, M, A, wave, dropped);
   } else {

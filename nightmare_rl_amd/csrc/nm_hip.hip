@@ -232,8 +232,10 @@ template <class real> struct Env : nm_env {
     memset(&M, 0, sizeof M);
     memset(&A, 0, sizeof A);
     T.fill_scalars(M, cfg);
-    if (const char* e = getenv("NM_MEASURE_PGS_ITERS")) M.pgs_iters = atoi(e);        // measurement only (results change): cost per sweep
+#ifdef NM_MEASURE   // measurement builds only (results change): cost per solver sweep
+    if (const char* e = getenv("NM_MEASURE_PGS_ITERS")) M.pgs_iters = atoi(e);
     if (const char* e = getenv("NM_MEASURE_NOSLIP_ITERS")) M.noslip_iters = atoi(e);
+#endif
     if (slab_init((T.hullv.size() + T.hullnv.size()) * sizeof(real) + (size_t)n * 300 * sizeof(real) + (size_t)n * 64 + (1u << 20))) return 1;
     if (upload(&M.hullv, T.hullv) || upload(&M.hullnv, T.hullnv)) return 1;
     A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
@@ -536,7 +538,9 @@ int nm_set_feet_state(nm_env* env, const double* air, const unsigned char* last,
 int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_cmd_u(u); }
 int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
+#ifdef NM_MEASURE   // include/nightmare_hip_measure.h: not part of the shipped ABI
 int nm_set_ablation(nm_env* env, int32_t mask) { NEED(env); env->set_ablate(mask); return 0; }
+#endif
 int nm_set_observation_noise(nm_env* env, const double* vec) { NEED(env); return env->set_noise(vec); }
 int nm_set_noise_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_noise_u(u); }
 int nm_set_state_record(nm_env* env, int32_t idx) { NEED(env); return env->set_record(idx); }

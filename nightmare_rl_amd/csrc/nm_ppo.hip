@@ -1004,8 +1004,10 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
   }
   for (int j = 0; j < h->A; j++) map.push_back(-(j + 1));
   h->nparam = (int)map.size();
+  // from here on a failure must release the handle (and what it already owns)
+#define PPO_CHK_H(x) do { if ((x) != hipSuccess) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: " #x " failed"); } } while (0)
   hipDeviceProp_t prop;
-  PPO_CHK(hipGetDeviceProperties(&prop, device));
+  PPO_CHK_H(hipGetDeviceProperties(&prop, device));
   h->nwg = prop.multiProcessorCount;
   size_t pft = 0, pbt = 0;
   for (int l = 0; l < n_layers; l++) {
@@ -1018,10 +1020,11 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
             hipMalloc((void**)&h->partial, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)) == hipSuccess &&
             hipMalloc((void**)&h->grad, (map.size() + 1) * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->state, 8 * sizeof(float)) == hipSuccess;
   if (!ok) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: hipMalloc failed"); }
-  PPO_CHK(hipMemcpy(h->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
-  PPO_CHK(hipMemset(h->Wm, 0, (size_t)h->wm_total * sizeof(float)));
-  PPO_CHK(hipMemset(h->state, 0, 8 * sizeof(float)));
-  PPO_CHK(hipMemset(h->partial, 0, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)));
+  PPO_CHK_H(hipMemcpy(h->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
+  PPO_CHK_H(hipMemset(h->Wm, 0, (size_t)h->wm_total * sizeof(float)));
+  PPO_CHK_H(hipMemset(h->state, 0, 8 * sizeof(float)));
+  PPO_CHK_H(hipMemset(h->partial, 0, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)));
+#undef PPO_CHK_H
   for (int l = 0; l < n_layers; l++) { n.pf[l] = h->pf + h->pf_off[l]; n.pb[l] = h->pb + h->pb_off[l]; }
   *out = h;
   return 0;

@@ -28,9 +28,14 @@ def gather_returns(local_returns, total_envs=None):
         out = torch.empty(sum(counts), dtype=local_returns.dtype, device=local_returns.device)
         dist.all_gather_into_tensor(out, local_returns.contiguous())
         return out
-    parts = [torch.empty(c, dtype=local_returns.dtype, device=local_returns.device) for c in counts]
-    dist.all_gather(parts, local_returns.contiguous())
-    return torch.cat(parts)
+    # unequal shards (total not a multiple of the rank count): neither gloo nor RCCL gathers ragged tensors - pad to the longest shard,
+    # still ONE collective, then drop the padding
+    m = max(counts)
+    padded = torch.zeros(m, dtype=local_returns.dtype, device=local_returns.device)
+    padded[:local_returns.numel()] = local_returns
+    out = torch.empty(world * m, dtype=local_returns.dtype, device=local_returns.device)
+    dist.all_gather_into_tensor(out, padded)
+    return torch.cat([out[r * m:r * m + c] for r, c in enumerate(counts)])
 
 
 def global_advantage_stats(adv):

@@ -3,8 +3,10 @@ MI355X-native step kernel. Same constructor, attributes and return tuples; state
 asynchronous on the current torch stream.
 
 Differences a caller can observe (all documented in DESIGN.md):
-  * returned tensors are views of persistent device buffers, valid until the next step() (the reference returns
-    fresh CPU tensors, :311)
+  * returned tensors are views of persistent device buffers (the reference returns fresh CPU tensors, :311). The observation
+    returned by step t stays untouched through step t+1 (two buffers, alternating), so a caller that keeps it across the next
+    env.step and copies it afterwards - rsl_rl's PPO.act -> env.step -> storage.add_transitions - stores what the policy saw;
+    rewards / dones / time_outs are valid until the next step()
   * commands come from a counter-based generator keyed by (seed, global env id) instead of numpy's global RNG (:327-330)
   * no viewer (`cfg.viewer.render` must be False); `cfg.viewer.record_states` writes the reference's pickle log (:261-272)
     at the price of one device sync per step
@@ -26,7 +28,8 @@ from .nightmare_v3_config import NightmareV3Config
 
 class NightmareV3Env:
     def __init__(self, cfg: NightmareV3Config, log_dir="/tmp/nightmare_v3/logs", num_threads=1, *, device=None, seed=0,
-                 env_id_offset=0, dtype=torch.float32):
+                 env_id_offset=0, dtype=torch.float32, lib=None):
+        """lib: a loaded library object other than the shipped one (_lib.load_measure(): measurement scripts and one test only)."""
         self.cfg = cfg
         self.log_dir = log_dir
         self.thread_num = num_threads  # accepted for API parity; the GPU path has no host threads
@@ -42,7 +45,7 @@ class NightmareV3Env:
             raise ValueError("tibia/body_contact_mode: 0 do nothing, 1 penalize on contact, 2 terminate on contact")
         if not torch.cuda.is_available():
             raise _lib.NightmareHipError("NightmareV3Env needs a HIP device: there is no CPU path")
-        L = _lib.load()
+        L = lib if lib is not None else _lib.load()
         self._L = L
         dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
         if dev.type != "cuda":
@@ -62,7 +65,7 @@ class NightmareV3Env:
             raise ValueError("cfg.commands.resampling_time must be at least one env step (reference :235 takes a modulo by it)")
         # reward table: zero scales dropped, the rest x dt (reference :123-128). Every name the reference has a _reward_ function
         # for (:399-497) is compiled; a name without one (`collision`, `feet_stumble`, config :95-96) fails like upstream's getattr.
-        names = _lib.reward_names()
+        names = [L.nm_reward_name(i).decode() for i in range(_lib.NUM_REWARDS)]
         for key in list(self.reward_scales.keys()):
             if self.reward_scales[key] == 0:
                 self.reward_scales.pop(key)
@@ -98,10 +101,13 @@ class NightmareV3Env:
         c.base_height_target, c.max_contact_force = float(cfg.rewards.base_height_target), float(cfg.rewards.max_contact_force)
         self._dtype = _lib.DTYPE_F64 if dtype == torch.float64 else _lib.DTYPE_F32
         h = C.c_void_p()
-        _lib.check(L.nm_create(C.byref(c), self.num_envs, self.device.index or 0, int(seed), int(env_id_offset), self._dtype, C.byref(h)))
+        self._ck(L.nm_create(C.byref(c), self.num_envs, self.device.index or 0, int(seed), int(env_id_offset), self._dtype, C.byref(h)))
         self._h = h
         N, dev = self.num_envs, self.device
-        self.obs_buf = torch.zeros((N, self.num_obs), dtype=torch.float32, device=dev)
+        # two observation buffers, written alternately: the tensor handed out by step t is not overwritten by step t+1
+        self._obs_pair = torch.zeros((2, N, self.num_obs), dtype=torch.float32, device=dev)
+        self._obs_idx = 0
+        self.obs_buf = self._obs_pair[0]
         self.privileged_obs_buf = None
         self.rew_buf = torch.zeros(N, dtype=torch.float32, device=dev)
         self.reset_buf = torch.ones(N, dtype=torch.int64, device=dev)
@@ -115,12 +121,12 @@ class NightmareV3Env:
         self.noise_scale_vec = self._noise_scale_vec(cfg)
         self.add_noise = bool(cfg.noise.add_noise)
         if self.add_noise:
-            _lib.check(L.nm_set_observation_noise(h, self.noise_scale_vec.ctypes.data_as(C.c_void_p)))
+            self._ck(L.nm_set_observation_noise(h, self.noise_scale_vec.ctypes.data_as(C.c_void_p)))
         # state log of env 0 (reference :261-272; reader open_custom_play.py:50-66)
         self.recorded_states = []
         self._rec_time = 0.0
         if cfg.viewer.record_states:
-            _lib.check(L.nm_set_state_record(h, 0))
+            self._ck(L.nm_set_state_record(h, 0))
 
     def _noise_scale_vec(self, cfg):
         ns, lvl, osc = cfg.noise.noise_scales, cfg.noise.noise_level, self.obs_scales
@@ -142,13 +148,13 @@ class NightmareV3Env:
     def set_noise_uniforms(self, u=None):
         """RNG-free noise for parity tests: [N,66] uniforms in [0,1) used instead of the generator (None = generator)."""
         u = None if u is None else np.ascontiguousarray(u, np.float64).reshape(self.num_envs, self.num_obs)
-        _lib.check(self._L.nm_set_noise_uniforms(self._h, None if u is None else u.ctypes.data_as(C.c_void_p)))
+        self._ck(self._L.nm_set_noise_uniforms(self._h, None if u is None else u.ctypes.data_as(C.c_void_p)))
 
     def _record_state(self):
         # reference :261-272: when env 0 resets, dump what was logged so far, then log (time, qpos, qvel, act) of env 0
         # as it is after the physics and before reset_idx. This model has no actuator state: act is empty.
         qpos, qvel, nbad = np.empty(25), np.empty(24), C.c_int32(0)
-        _lib.check(self._L.nm_get_state_record(self._h, qpos.ctypes.data_as(C.c_void_p), qvel.ctypes.data_as(C.c_void_p), C.byref(nbad)))
+        self._ck(self._L.nm_get_state_record(self._h, qpos.ctypes.data_as(C.c_void_p), qvel.ctypes.data_as(C.c_void_p), C.byref(nbad)))
         if bool(self.reset_buf[0].item()):
             os.makedirs(self.log_dir, exist_ok=True)
             with open(f"{self.log_dir}/{int(time.time())}.pkl", "wb") as f:
@@ -157,6 +163,9 @@ class NightmareV3Env:
         sim_dt = 0.008 * self.cfg.control.decimation
         self._rec_time = sim_dt if nbad.value else self._rec_time + sim_dt   # mj_resetData restarts data.time
         self.recorded_states.append((self._rec_time, qpos, qvel, np.zeros(0)))
+
+    def _ck(self, rc):
+        _lib.check(rc, self._L)
 
     # ------------------------------------------------------------------ reference surface
     def _stream(self):
@@ -185,7 +194,9 @@ class NightmareV3Env:
         if a.shape[1] != 18 or not a.is_contiguous():
             a = a[:, :18].contiguous()
         ep = self._eplen()
-        _lib.check(self._L.nm_step(self._h, a.data_ptr(), ep.data_ptr(), self.obs_buf.data_ptr(), self.rew_buf.data_ptr(),
+        self._obs_idx ^= 1
+        self.obs_buf = self._obs_pair[self._obs_idx]
+        self._ck(self._L.nm_step(self._h, a.data_ptr(), ep.data_ptr(), self.obs_buf.data_ptr(), self.rew_buf.data_ptr(),
                                    self.reset_buf.data_ptr(), self.time_out_buf.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
         self._last_actions = a  # keep the input alive until the kernel has read it
         self.common_step_counter += 1
@@ -207,7 +218,7 @@ class NightmareV3Env:
     def step_physics(self, actions):
         """mj_step x decimation only (no rewards/obs/reset): the 'dynamics+contact kernel' configuration."""
         a = actions.to(device=self.device, dtype=torch.float32)[:, :18].contiguous()
-        _lib.check(self._L.nm_step_physics(self._h, a.data_ptr(), self._stream()))
+        self._ck(self._L.nm_step_physics(self._h, a.data_ptr(), self._stream()))
         self._last_actions = a
 
     def reset_idx(self, env_ids):
@@ -219,7 +230,7 @@ class NightmareV3Env:
                 return
             ids, n = idsa.ctypes.data_as(C.c_void_p), int(idsa.size)
         ep = self._eplen()
-        _lib.check(self._L.nm_reset(self._h, ids, n, ep.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
+        self._ck(self._L.nm_reset(self._h, ids, n, ep.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
         self._fill_extras()
 
     def reset(self):
@@ -240,53 +251,53 @@ class NightmareV3Env:
     def get_state(self):
         N = self.num_envs
         qpos, qvel, qw = np.empty((N, 25)), np.empty((N, 24)), np.empty((N, 24))
-        _lib.check(self._L.nm_get_state(self._h, qpos.ctypes.data, qvel.ctypes.data, qw.ctypes.data))
+        self._ck(self._L.nm_get_state(self._h, qpos.ctypes.data, qvel.ctypes.data, qw.ctypes.data))
         return qpos, qvel, qw
 
     def set_state(self, qpos=None, qvel=None, qacc_warmstart=None):
         arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (qpos, qvel, qacc_warmstart)]
-        _lib.check(self._L.nm_set_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+        self._ck(self._L.nm_set_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
     def get_buffers(self):
         N = self.num_envs
         out = dict(dof_pos=np.empty((N, 18)), dof_vel=np.empty((N, 18)), actions=np.empty((N, 18)), commands=np.empty((N, 3)),
                    episode_sums=np.empty((N, _lib.NUM_REWARDS)))
-        _lib.check(self._L.nm_get_buffers(self._h, *[out[k].ctypes.data for k in ("dof_pos", "dof_vel", "actions", "commands", "episode_sums")]))
+        self._ck(self._L.nm_get_buffers(self._h, *[out[k].ctypes.data for k in ("dof_pos", "dof_vel", "actions", "commands", "episode_sums")]))
         return out
 
     def set_buffers(self, dof_pos=None, dof_vel=None, actions=None, commands=None, episode_sums=None):
         arrs = [None if a is None else np.ascontiguousarray(a, np.float64) for a in (dof_pos, dof_vel, actions, commands, episode_sums)]
-        _lib.check(self._L.nm_set_buffers(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+        self._ck(self._L.nm_set_buffers(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
     def get_feet_state(self):
         """(feet_air_time [N,6] f64, last_contacts [N,6] u8, last_contacts_filt [N,6] u8): state of _reward_feet_air_time (:90-93)."""
         N = self.num_envs
         air, last, filt = np.empty((N, 6)), np.empty((N, 6), np.uint8), np.empty((N, 6), np.uint8)
-        _lib.check(self._L.nm_get_feet_state(self._h, air.ctypes.data, last.ctypes.data, filt.ctypes.data))
+        self._ck(self._L.nm_get_feet_state(self._h, air.ctypes.data, last.ctypes.data, filt.ctypes.data))
         return air, last, filt
 
     def set_feet_state(self, air=None, last=None, filt=None):
         f = lambda a, t: None if a is None else np.ascontiguousarray(a, t)
         arrs = [f(air, np.float64), f(last, np.uint8), f(filt, np.uint8)]
-        _lib.check(self._L.nm_set_feet_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
+        self._ck(self._L.nm_set_feet_state(self._h, *[None if a is None else a.ctypes.data for a in arrs]))
 
     def set_command_uniforms(self, u):
         a = None if u is None else np.ascontiguousarray(u, np.float64).reshape(self.num_envs, 4)
-        _lib.check(self._L.nm_set_command_uniforms(self._h, None if a is None else a.ctypes.data))
+        self._ck(self._L.nm_set_command_uniforms(self._h, None if a is None else a.ctypes.data))
 
     def counters(self):
         out = np.zeros(3, np.int64)
-        _lib.check(self._L.nm_get_counters(self._h, out.ctypes.data))
+        self._ck(self._L.nm_get_counters(self._h, out.ctypes.data))
         return dict(contacts_dropped=int(out[0]), bad_state_resets=int(out[1]), hull_search_fallbacks=int(out[2]))
 
     def set_debug_buffer(self, t):
         self._dbg = t
-        _lib.check(self._L.nm_set_debug_buffer(self._h, None if t is None else t.data_ptr()))
+        self._ck(self._L.nm_set_debug_buffer(self._h, None if t is None else t.data_ptr()))
 
     def profile(self, enable):
         """(sum_ms, count) of step-kernel HIP-event times since the last call; sets event recording on/off."""
         ms, cnt = C.c_double(0), C.c_int64(0)
-        _lib.check(self._L.nm_profile(self._h, int(bool(enable)), C.byref(ms), C.byref(cnt)))
+        self._ck(self._L.nm_profile(self._h, int(bool(enable)), C.byref(ms), C.byref(cnt)))
         return ms.value, cnt.value
 
     @property

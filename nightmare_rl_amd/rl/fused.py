@@ -81,6 +81,14 @@ class FusedCollector:
     def record(self, storage, rewards, dones, time_outs, gamma, cur_ret, cur_len, fin, ep=None):
         """ep = (ep_stats [K] f32, ep_idx [n] int32, ep_acc [n] f32) device tensors: ep_acc += ep_stats[ep_idx] in the same launch."""
         s = storage.step
+        # the kernel reads raw pointers: float32 rewards / time_outs, int64 dones, contiguous, on this device. An env in the style of
+        # rsl_rl / legged_gym may hand over bool dones or time_outs and float64 rewards: convert instead of misreading them.
+        want = lambda t, dt: t if (t.dtype == dt and t.is_contiguous() and t.device == self.device) else t.to(device=self.device, dtype=dt).contiguous()
+        rewards, dones = want(rewards.reshape(-1), torch.float32), want(dones.reshape(-1), torch.int64)
+        time_outs = None if time_outs is None else want(time_outs.reshape(-1), torch.float32)
+        if rewards.numel() != self.N or dones.numel() != self.N or (time_outs is not None and time_outs.numel() != self.N):
+            raise ValueError(f"record: rewards / dones / time_outs must hold {self.N} entries")
+        self._keep = (rewards, dones, time_outs)          # converted copies stay alive until the launch has read them
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         eps, epi, n_ep, epa = (ep[0].data_ptr(), ep[1].data_ptr(), int(ep[1].numel()), ep[2].data_ptr()) if ep is not None else (None, None, 0, None)
         _lib.check(self._L.nm_ppo_record(rewards.data_ptr(), dones.data_ptr(), None if time_outs is None else time_outs.data_ptr(),
@@ -207,7 +215,21 @@ class FusedUpdate:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._L.nm_ppo_get_state(self._h, out, int(reset_sums), stream))
         keys = ("lr", "steps", "kl", "value_loss_sum", "surrogate_loss_sum", "minibatches", "clip_coef", "grad_norm")
-        return dict(zip(keys, [float(x) for x in out]))
+        st = dict(zip(keys, [float(x) for x in out]))
+        self.step_count = int(round(st["steps"]))         # the device's Adam step counter is the authority
+        self.publish_step()
+        return st
+
+    def publish_step(self):
+        """Adam's step count into the torch optimizer's state (what a checkpoint saves next to the moments; rsl_rl saves
+        optimizer.state_dict(), reference train.py:49-52 resumes from it)."""
+        for p in self.params:
+            st = self.opt.state.get(p)
+            if st is not None:
+                if torch.is_tensor(st.get("step")):
+                    st["step"].fill_(float(self.step_count))
+                else:
+                    st["step"] = torch.tensor(float(self.step_count))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -36,12 +36,20 @@ class PPO:
         if (critic_obs_shape is None or critic_obs_shape[0] is None) and FusedCollector.supported(self.actor_critic, self.device):
             # the update first: it re-homes the parameters in one flat vector, which the collector then reads
             if FusedUpdate.supported(self.actor_critic, self.device):
-                self.fused_update = FusedUpdate(self.actor_critic, self.optimizer, self.device, self.learning_rate)
+                try:
+                    self.fused_update = FusedUpdate(self.actor_critic, self.optimizer, self.device, self.learning_rate)
+                except Exception as e:     # nm_ppo_create can still refuse (dW tiles per wave, device memory): keep the torch update
+                    import warnings
+                    warnings.warn(f"fused PPO update unavailable for this network ({e}); using the torch update path")
+                    self.fused_update = None
             rank = dist.get_rank() if _world() > 1 else 0     # every rank draws its own action noise
             self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=(torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF, update=self.fused_update)
 
     def after_load(self):
-        """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow."""
+        """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow. The adaptive-KL schedule resumes
+        from the learning rate the checkpoint's optimizer carried (param_groups[0]['lr']), not from the configured initial rate."""
+        if self.optimizer.param_groups:
+            self.learning_rate = float(self.optimizer.param_groups[0]["lr"])
         if getattr(self, "fused_update", None) is not None:
             self.fused_update.sync(self.learning_rate)
 

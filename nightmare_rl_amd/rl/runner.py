@@ -110,12 +110,19 @@ class OnPolicyRunner:
                     if ep_acc is None:
                         ep_acc = torch.zeros_like(e)
                     ep_acc.add_(e)
+            # The rollout starts from a buffer of its own: a captured graph reads and writes fixed addresses, and an env that
+            # alternates its observation buffers ends an odd-length rollout in the buffer the next replay would NOT read first.
+            if on_gpu and priv is None:
+                if state.get("stage") is None:
+                    state["stage"] = torch.empty_like(o)
+                state["stage"].copy_(o)
+                o = co = state["stage"]
             state["obs"], state["critic_obs"] = o, co
 
+        on_gpu = torch.device(dev).type == "cuda"
         want_graph = bool(self.cfg.get("graph_rollout", True)) and torch.device(dev).type == "cuda" and hasattr(env, "_h") \
             and not getattr(env, "add_noise", False) and not getattr(getattr(env.cfg, "viewer", None), "record_states", False)
         graph = None
-        on_gpu = torch.device(dev).type == "cuda"
         ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else (None, None)
         for it in range(self.current_learning_iteration, tot_iter):
             start = time.time()

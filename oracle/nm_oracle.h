@@ -82,6 +82,9 @@ void nmo_env_reset_idx(nmo_env* e, const int32_t* ids, int n, const double* cmd_
  * resample, (x,yaw) for the reset resample; NULL -> internal counter RNG. Outputs may be NULL. */
 void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done,
                   float* time_outs, double* obs64, double* rew64);
+/* dynamics + contact only (BASELINE config 2; reference simple_test.py:25-45): servo command from the live joint angles, then
+ * mj_step(model, data[i], decimation) over the threads. No epilogue; env-level buffers untouched. */
+void nmo_env_step_physics(nmo_env* e, const float* actions);
 /* non-default reward table / contact modes (config.py:17-21, 77-100). reward_scales[NMO_NREW] are the RAW config scales (x dt is
  * applied here, env.py:123-128; 0 drops the term); NULL keeps the current ones */
 void nmo_env_configure(nmo_env* e, const double* reward_scales, int tibia_mode, double tibia_max_force, int body_mode, double body_max_force,

@@ -183,6 +183,29 @@ static float np_sum_f32(const float* a, int n) {
   return res;
 }
 
+/* BASELINE config 2, "dynamics + contact only" (the shape of the reference's simple_test.py:25-45: ctrl, then mj_step(model, data[i],
+ * decimation) fanned out over threads; no observation / reward / reset): E1 with the servo command taken from the LIVE joint angles
+ * qpos[7:] (there is no env buffer to be stale in this configuration), then E2. The env-level buffers are left alone. */
+void nmo_env_step_physics(nmo_env* e, const float* actions) {
+  const int N = e->N;
+  const double default_pos[3] = {0.0, kPi / 5, 0.0};
+  for (int i = 0; i < N; i++)
+    for (int j = 0; j < 18; j++) {
+      float a = actions[i * 18 + j] * ACTION_SCALE_F;
+      a = a < -CLIP_ACTIONS_F ? -CLIP_ACTIONS_F : (a > CLIP_ACTIONS_F ? CLIP_ACTIONS_F : a);
+      e->data[i].ctrl[j] = (((double)a - default_pos[j % 3]) - e->data[i].qpos[7 + j]) * P_GAIN;
+    }
+#pragma omp parallel for num_threads(e->nthreads) schedule(static)
+  for (int i = 0; i < N; i++) {
+#ifdef _OPENMP
+    nmo_scratch* s = &e->scratch[omp_get_thread_num()];
+#else
+    nmo_scratch* s = &e->scratch[0];
+#endif
+    nmo_step(&e->data[i], s, DECIMATION);
+  }
+}
+
 void nmo_env_step(nmo_env* e, const float* actions, const double* cmd_u, float* obs, float* rew, int64_t* done,
                   float* time_outs, double* obs64, double* rew64) {
   const int N = e->N;

@@ -90,6 +90,7 @@ def lib():
         L.nmo_env_destroy.argtypes = [C.c_void_p]
         L.nmo_env_reset_idx.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         L.nmo_env_step.argtypes = [C.c_void_p] + [C.c_void_p] * 8
+        L.nmo_env_step_physics.argtypes = [C.c_void_p, C.c_void_p]
         L.nmo_env_set_noise.argtypes = [C.c_void_p] * 3
         L.nmo_env_configure.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_int, C.c_double, C.c_double, C.c_double]
         L.nmo_env_get_feet_state.argtypes = [C.c_void_p] * 4
@@ -198,6 +199,11 @@ class OracleEnv:
         self.L.nmo_env_step(self.h, _ptr(a), _ptr(cu), _ptr(obs), _ptr(rew), _ptr(done), _ptr(to), _ptr(obs64), _ptr(rew64))
         self.obs64, self.rew64 = obs64, rew64
         return obs, rew, done, to
+
+    def step_physics(self, actions):
+        """mj_step x decimation only (BASELINE config 2; reference simple_test.py:25-45)."""
+        a = np.ascontiguousarray(actions, np.float32).reshape(self.N, 18)
+        self.L.nmo_env_step_physics(self.h, _ptr(a))
 
     def set_noise(self, noise_scale_vec=None, u=None):
         f = lambda a: None if a is None else np.ascontiguousarray(a, np.float64)

@@ -6,11 +6,12 @@ from nightmare_rl_amd.envs.nightmare_v3_env import NightmareV3Env
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = NightmareV3Config(); cfg.env.num_envs = N
 acts = (torch.rand(16, N, 18, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda()
-env = NightmareV3Env(cfg, seed=0); env.reset()
 mask = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+from nightmare_rl_amd import _lib
+env = NightmareV3Env(cfg, seed=0, lib=_lib.load_measure() if mask else None); env.reset()   # stage skipping needs the -DNM_MEASURE build
 for i in range(300): env.step(acts[i % 16])          # settle with the real kernel
 q0 = env.get_state()
-env._L.nm_set_ablation(env._h, mask)
+if mask: env._L.nm_set_ablation(env._h, mask)
 res = []
 for rep in range(3):
     if mask: env.set_state(*q0)                       # ablated physics drifts: restart every rep from the settled state

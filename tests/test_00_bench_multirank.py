@@ -52,3 +52,37 @@ def test_two_rank_train_py_runs_the_fused_data_parallel_loop(tmp_path):
     lines = [l for l in r.stdout.splitlines() if l.startswith("it ")]
     assert len(lines) == 4 and "nan" not in lines[-1], lines
     assert "contacts_dropped': 0" in r.stdout
+
+
+# BASELINE configs[3] / configs[4] name 8 ranks x 4096 envs. This pool's process guard allows at most 6 processes on one card, so the
+# rehearsal on the one-GPU box keeps the TOTAL (32768 envs) and uses 4 ranks x 8192; the 8-shard layout itself is checked bit for bit in
+# tests/test_gpu_configs.py::test_config4_32768_envs_equal_eight_shards_of_4096, and 8 gloo ranks on CPU tensors in
+# tests/test_sharding_gloo.py::test_eight_rank_gather_is_ordered_by_global_env_id.
+def test_four_rank_bench_at_the_config4_job_size():
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "100", "--warmup", "20",
+           "--envs-per-gpu", "8192"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 4 and out["config"]["envs_per_gpu"] == 8192 and out["scaling"] == "weak"
+    assert out["collectives_timed"] >= 2                       # step 80 of the rollout horizon and the last timed step
+    assert out["gather_order_mismatches"] == 0                 # every rank found its own returns at [rank*E, (rank+1)*E) of the gathered vector
+    assert out["counters"]["contacts_dropped"] == 0 and out["counters"]["bad_state_resets"] == 0
+    assert abs(out["value"] - 4 * 8192 * 100 / (out["ms_per_step"] * 100 / 1e3)) < 1e-6 * out["value"]
+
+
+def test_four_rank_train_py_at_the_config5_job_size(tmp_path):
+    """BASELINE configs[4]: train.py at 32768 envs in total, sharded by global env id over the ranks, fused collection per rank, fused
+    data-parallel update (one all-reduce of gradient | KL per mini-batch): 3 iterations, the replicas end bit-identical, no contact
+    dropped, no bad-state reset on any shard."""
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", "29539", os.path.join(ROOT, "train.py"), "-e", "32768", "--iters", "3"]
+    r = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("it ")]
+    assert len(lines) == 3 and "nan" not in lines[-1], lines
+    assert "replicas: 4 ranks, max |parameter difference to rank 0| = 0.000e+00" in r.stdout, r.stdout[-1500:]
+    assert "'contacts_dropped': 0" in r.stdout and "'bad_state_resets': 0" in r.stdout

@@ -110,3 +110,41 @@ def test_two_rank_ppo_keeps_replicas_identical():
     np.testing.assert_array_equal(w0, w1)
     assert lr0 == lr1
     assert r0 == r1                                      # the logged step reward is the all-reduced mean
+
+
+def _gather8_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from nightmare_rl_amd.distributed import gather_returns, shard_range
+    total = 8 * 4096                                    # BASELINE configs[3]: 32768 envs, rank g owns [g*4096, (g+1)*4096)
+    lo, hi = shard_range(total, rank, world)
+    mine = torch.arange(lo, hi, dtype=torch.float32) * 0.5 + 1.0          # a value that names its global env id
+    allret = gather_returns(mine, total_envs=total)
+    ragged_total = total + 3                            # remainder spread over the first ranks: unequal shard sizes
+    rlo, rhi = shard_range(ragged_total, rank, world)
+    ragged = gather_returns(torch.arange(rlo, rhi, dtype=torch.float32), total_envs=ragged_total)
+    q.put((rank, lo, hi, bool(torch.equal(allret, torch.arange(total, dtype=torch.float32) * 0.5 + 1.0)),
+           bool(torch.equal(ragged, torch.arange(ragged_total, dtype=torch.float32)))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_gather_is_ordered_by_global_env_id():
+    """The collective of BASELINE configs[3] with the node's real rank count: 8 gloo ranks x 4096 envs, one all-gather, every rank
+    receives all 32768 returns ordered by global env id (and a ragged split keeps the order too)."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_gather8_worker, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert [(r[1], r[2]) for r in res] == [(g * 4096, (g + 1) * 4096) for g in range(8)]
+    assert all(r[3] and r[4] for r in res)

@@ -57,8 +57,23 @@ def main():
         print(f"Loading model from: {path}")
         runner.load(path)
     runner.learn(num_learning_iterations=args.iters if args.iters is not None else train_cfg.runner.max_iterations, init_at_random_ep_len=True)
+    counters = env.counters()                                # contacts dropped (provably 0), MuJoCo-style bad-state resets, search fallbacks
+    if world > 1:
+        # every rank must hold the same policy after the data-parallel updates: the largest difference to rank 0's parameters, and the
+        # env counters summed over the shards
+        dev = f"cuda:{local_rank}"
+        flat = torch.cat([p.detach().reshape(-1).float() for p in runner.alg.actor_critic.parameters()]).to(dev)
+        ref = flat.clone()
+        dist.broadcast(ref, 0)
+        diff = (flat - ref).abs().max().reshape(1)
+        dist.all_reduce(diff, op=dist.ReduceOp.MAX)
+        c = torch.tensor([counters[k] for k in sorted(counters)], device=dev, dtype=torch.float64)
+        dist.all_reduce(c)
+        counters = {k: int(v) for k, v in zip(sorted(counters), c.tolist())}
+        if rank == 0:
+            print(f"replicas: {world} ranks, max |parameter difference to rank 0| = {float(diff):.3e}", flush=True)
     if rank == 0:
-        print("env counters:", env.counters(), flush=True)   # contacts dropped by the per-env cap, MuJoCo-style bad-state resets
+        print("env counters:", counters, flush=True)
     if world > 1:
         dist.destroy_process_group()
 
