@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_gpu_parity import check_outlier, kTol, make_env
+from test_gpu_parity import check_outlier, kOutlierBound, kTol, make_env
 
 pytestmark = pytest.mark.gpu
 
@@ -58,7 +58,11 @@ def test_config2_physics_only_4096_envs_fp64_kernel_equals_the_oracle(oracle_mod
 def test_config2_physics_only_4096_envs_fp32_kernel_within_stated_tolerance(oracle_mod):
     """The production fp32 kernel in the same configuration: the state after one physics-only step is within 1e-4 of the oracle's in
     observation units; an env-step above it must be a proven discrete collision decision of bounded size (the contract of
-    test_fp32_outliers_are_proven_discrete_events)."""
+    test_fp32_outliers_are_proven_discrete_events). One bound differs from that test's: here the POST-step velocity is compared
+    (step() reports the velocity of the last forward pass, env.py:217), so a contact that exists in one precision only (`act`: its
+    penetration is within 2e-7 m of zero) shows up with the whole approach speed of that vertex it removes: <= 0.5 m/s x the
+    lin_vel scale 2 = 1.0 (measured on MI355X: one such env-step in 40 960, 0.32)."""
+    bounds = dict(kOutlierBound, act=1.0)
     N, T = 4096, 10
     ora, rng = _settled_population(oracle_mod, N, 45, seed=32)
     env = make_env(N, seed=32)
@@ -74,7 +78,7 @@ def test_config2_physics_only_4096_envs_fp32_kernel_within_stated_tolerance(orac
         e = _obs_equivalent_error(q, v, oq, ov)
         errs.append(e)
         for i in np.nonzero(e > kTol)[0]:
-            check_outlier(oracle_mod, e[i], q0[i], v0[i], w0[i], a[i], q0[i, 7:], f"t={t} env={i}")
+            check_outlier(oracle_mod, e[i], q0[i], v0[i], w0[i], a[i], q0[i, 7:], f"t={t} env={i}", bounds=bounds)
             nout += 1
     e = np.concatenate(errs)
     assert np.median(e) < 2e-6 and np.percentile(e, 99) < 1e-5, (np.median(e), np.percentile(e, 99))
@@ -108,7 +112,7 @@ def test_config4_32768_envs_equal_eight_shards_of_4096():
 
     full, fcmd, fc = run(N, 0)
     assert fc["contacts_dropped"] == 0 and fc["bad_state_resets"] == 0
-    nto = sum(int(o[3].sum()) for o in full)
+    nto = sum(int((o[3] * o[2]).sum()) for o in full)      # extras['time_outs'] is only refreshed by a step in which an env reset (env.py:344)
     assert 0.9 * (N // 2) <= nto <= N // 2                                  # the late half times out once (minus the few that fell first)
     for g in range(G):
         shard, scmd, _ = run(E, g * E)

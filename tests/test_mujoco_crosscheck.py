@@ -24,27 +24,95 @@ def test_model_constants_match_the_compiled_tables():
     assert abs(m.stat.meaninertia - float(T["meaninertia"])) < 1e-6 * m.stat.meaninertia
 
 
+def _compare_step(m, d, p, q, v, w, ctrl, where):
+    """One teacher-forced mj_step on both sides from the same (qpos, qvel, qacc_warmstart, ctrl): everything a wrong collision,
+    constraint or solver stage would move - contact count / order / geometry, constraint forces, accelerations, sensors, state."""
+    mujoco.mj_resetData(m, d)
+    d.qpos[:], d.qvel[:], d.qacc_warmstart[:], d.ctrl[:] = q, v, w, ctrl
+    p.reset()
+    p.qpos[:], p.qvel[:], p.qacc_warmstart[:], p.ctrl[:] = q, v, w, ctrl
+    mujoco.mj_step(m, d)
+    p.step(1)
+    n = p.d.ncon
+    assert d.ncon == n, (where, d.ncon, n)
+    for c in range(n):                                           # same contacts in the same order (PGS sweeps depend on it)
+        con = d.contact[c]
+        assert m.geom_bodyid[con.geom2] == p.con_body[c], (where, c)
+        assert max(m.geom_bodyid[con.geom1], 0) == max(p.con_body1[c], 0), (where, c)
+        np.testing.assert_allclose(con.pos, p.con_pos[c], atol=1e-9, err_msg=f"{where} contact {c} pos")
+        np.testing.assert_allclose(con.frame, np.asarray(p.con_frame[c]).reshape(-1), atol=1e-9, err_msg=f"{where} contact {c} frame")
+        assert abs(con.dist - p.con_dist[c]) < 1e-9, (where, c)
+    assert d.nefc == p.d.nefc == 4 * n, where
+    np.testing.assert_allclose(d.efc_force[: d.nefc], p.efc_force[: d.nefc], atol=1e-6, err_msg=f"{where} efc_force")
+    np.testing.assert_allclose(d.qacc, p.qacc, atol=1e-6, err_msg=f"{where} qacc")
+    np.testing.assert_allclose(d.qfrc_constraint, p.qfrc_constraint, atol=1e-7, err_msg=f"{where} qfrc_constraint")
+    np.testing.assert_allclose(p.qpos, d.qpos, atol=1e-9, err_msg=f"{where} qpos")
+    np.testing.assert_allclose(p.qvel, d.qvel, atol=1e-7, err_msg=f"{where} qvel")
+    np.testing.assert_allclose(p.qacc_warmstart, d.qacc_warmstart, atol=1e-6, err_msg=f"{where} warmstart")
+    np.testing.assert_allclose(p.sensordata, d.sensordata, atol=1e-6, err_msg=f"{where} sensordata")
+    np.testing.assert_allclose(np.asarray(p.cvel)[1], d.cvel[1], atol=1e-8, err_msg=f"{where} cvel[1]")      # what E3 reads (env.py:217-218)
+    np.testing.assert_allclose(np.asarray(p.xipos)[1], d.xipos[1], atol=1e-10)
+    return n
+
+
 def test_single_steps_match_mujoco(oracle_mod):
+    import parity_tools as pt
     m = mujoco.MjModel.from_xml_path(XML)
     d = mujoco.MjData(m)
     p = oracle_mod.Physics()
     rng = np.random.default_rng(0)
     ora = oracle_mod.OracleEnv(16, seed=1)
     ora.reset()
-    for t in range(60):                                  # states along a random-action rollout of the oracle, through touch-down
+    ncon = 0
+    for t in range(120):                                 # states along a random-action rollout of the oracle, through touch-down
         a = rng.uniform(-1, 1, (16, 18)).astype(np.float32)
         q, v, w = ora.get_state()
-        import parity_tools as pt
-        ctrl = [pt.servo_ctrl(a[i], ora.get_buffers()["dof_pos"][i]) for i in range(16)]    # what step() hands to the physics (E1)
+        dof_pos = ora.get_buffers()["dof_pos"]
         ora.step(a)
         i = t % 16
-        mujoco.mj_resetData(m, d)
-        d.qpos[:], d.qvel[:], d.qacc_warmstart[:], d.ctrl[:] = q[i], v[i], w[i], ctrl[i]
-        p.reset()
-        p.qpos[:], p.qvel[:], p.qacc_warmstart[:], p.ctrl[:] = q[i], v[i], w[i], ctrl[i]
-        mujoco.mj_step(m, d)
-        p.step(1)
-        assert d.ncon == p.d.ncon, t
-        np.testing.assert_allclose(p.qpos, d.qpos, atol=1e-9)
-        np.testing.assert_allclose(p.qvel, d.qvel, atol=1e-7)
-        np.testing.assert_allclose(p.sensordata, d.sensordata, atol=1e-6)
+        ncon += _compare_step(m, d, p, q[i], v[i], w[i], pt.servo_ctrl(a[i], dof_pos[i]), f"rollout t={t} env={i}")
+    assert ncon > 100
+
+
+def test_many_contact_states_match_mujoco(oracle_mod):
+    """The > 16-contact states of tests/golden/env_manycontacts.npz (a robot lying on folded legs, servos holding the pose): up to 20
+    simultaneous contacts, the matrix-free solver path of the HIP kernel."""
+    import parity_tools as pt
+    from conftest import load_golden
+    g = load_golden("env_manycontacts.npz")
+    m = mujoco.MjModel.from_xml_path(XML)
+    d = mujoco.MjData(m)
+    p = oracle_mod.Physics()
+    most = 0
+    T, N = g["actions"].shape[:2]
+    for t in range(1, T):
+        for i in range(N):
+            ctrl = pt.servo_ctrl(g["actions"][t][i], g["dof_pos"][t - 1][i])
+            most = max(most, _compare_step(m, d, p, g["qpos"][t - 1][i], g["qvel"][t - 1][i], g["qacc_warmstart"][t - 1][i], ctrl, f"manycontacts t={t} env={i}"))
+    assert most > 16
+
+
+def test_crossing_leg_states_match_mujoco(oracle_mod):
+    """Tibia-tibia contacts (libccd MPR inside MuJoCo vs the oracle's restatement): the crossing-leg population of
+    tests/test_self_collision.py, several steps of squeezing."""
+    import parity_tools as pt
+    from test_self_collision import crossing_states, squeeze_actions
+    m = mujoco.MjModel.from_xml_path(XML)
+    d = mujoco.MjData(m)
+    p = oracle_mod.Physics()
+    rng = np.random.default_rng(11)
+    n = 24
+    qpos, qvel = crossing_states(n, rng)
+    ora = oracle_mod.OracleEnv(n, seed=0)
+    qw = np.zeros((n, 24))
+    npair = 0
+    for t in range(10):
+        ora.set_state(qpos, qvel, qw)
+        dof_pos = ora.get_buffers()["dof_pos"]
+        a = squeeze_actions(n, rng)
+        for i in range(n):
+            _compare_step(m, d, p, qpos[i], qvel[i], qw[i], pt.servo_ctrl(a[i], dof_pos[i]), f"crossing t={t} env={i}")
+            npair += int((np.asarray(p.con_body1[: p.d.ncon]) > 0).sum())
+        ora.step(a)
+        qpos, qvel, qw = ora.get_state()
+    assert npair >= 10
