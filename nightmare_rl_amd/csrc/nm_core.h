@@ -686,46 +686,53 @@ template <class real> NM_FN bool ccd_eq(real a, real b) {
   real fa = vabs(a), fb = vabs(b);
   return ab < ccd_eps<real>() * (fb > fa ? fb : fa);
 }
-template <class real> NM_FN void hull_support(const Sh<real>& sh, const Model<real>& M, int g, const real* dir, real* out) {
-  typedef V<real> vr;
+// `real` is the precision of the env state (LDS image, hull table), `acc` the precision MPR computes in. The fp32 kernel runs MPR in
+// fp64 (acc = double): the portal refinement is a chain of discrete decisions on cross products of nearly parallel differences, and in
+// fp32 5 % of the env-steps with deeply interpenetrating tibias picked another portal than the fp64 reference (errors up to 8 in the
+// observation: profiles/r03_mpr_fp32_study.txt). The path is rare, wave-uniform and out of line, so the price is code size only.
+template <class acc, class real> NM_FN void hull_support(const Sh<real>& sh, const Model<real>& M, int g, const acc* dir, acc* out) {
+  typedef V<acc> vr;
   const V<int> lane = lane_id();
-  const real* R = sh.colR + 9 * g;
-  const real* p = sh.colp + 3 * g;
+  acc R[9], p[3];
+#pragma unroll
+  for (int j = 0; j < 9; j++) R[j] = (acc)sh.colR[9 * g + j];
+#pragma unroll
+  for (int j = 0; j < 3; j++) p[j] = (acc)sh.colp[3 * g + j];
   const real* cc = M.colc + kColN * g;
   const int nvert = (int)cc[5], vadr = (int)cc[6];
-  const real ld[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
-                      R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
+  const acc ld[3] = {R[0] * dir[0] + R[3] * dir[1] + R[6] * dir[2], R[1] * dir[0] + R[4] * dir[1] + R[7] * dir[2],
+                     R[2] * dir[0] + R[5] * dir[1] + R[8] * dir[2]};
   // two passes: wave max, then the lowest vertex index within kMprTie of it (tie-robust, see oracle hull_support)
-  vr best = vr(real(-1e30));
+  vr best = vr(acc(-1e30));
   for (int it = 0; it * NM_WAVE < nvert; it++) {
     V<int> vi = lane + it * NM_WAVE;
     VB ok = vi < nvert;
     V<int> ad = (sel(ok, vi, V<int>(0)) + vadr) * 4;
-    vr val = ld[0] * gldv(M.hullv, ad) + ld[1] * gldv(M.hullv, ad + 1) + ld[2] * gldv(M.hullv, ad + 2);
+    vr val = ld[0] * vcvt<acc>(gldv(M.hullv, ad)) + ld[1] * vcvt<acc>(gldv(M.hullv, ad + 1)) + ld[2] * vcvt<acc>(gldv(M.hullv, ad + 2));
     best = sel(ok & (val > best), val, best);
   }
-  real sv; int si;
+  acc sv; int si;
   wargmax(best, lane, &sv, &si);
-  vr neg = vr(real(-1e30));
   V<int> ifirst = V<int>(1 << 30);
   for (int it = 0; it * NM_WAVE < nvert; it++) {
     V<int> vi = lane + it * NM_WAVE;
     VB ok = vi < nvert;
     V<int> ad = (sel(ok, vi, V<int>(0)) + vadr) * 4;
-    vr val = ld[0] * gldv(M.hullv, ad) + ld[1] * gldv(M.hullv, ad + 1) + ld[2] * gldv(M.hullv, ad + 2);
-    ifirst = sel(ok & (val >= vr(sv - real(1e-7))) & (vi < ifirst), vi, ifirst);
+    vr val = ld[0] * vcvt<acc>(gldv(M.hullv, ad)) + ld[1] * vcvt<acc>(gldv(M.hullv, ad + 1)) + ld[2] * vcvt<acc>(gldv(M.hullv, ad + 2));
+    ifirst = sel(ok & (val >= vr(sv - acc(1e-7))) & (vi < ifirst), vi, ifirst);
   }
-  wargmax(to_real<real>(-ifirst), lane, &sv, &si);  // largest -index = lowest index
+  wargmax(to_real<acc>(-ifirst), lane, &sv, &si);  // largest -index = lowest index
   si = (int)(-sv);
-  const real* v = M.hullv + 4 * (vadr + si);
-  real t[3];
+  const real* vp = M.hullv + 4 * (vadr + si);
+  const acc v[3] = {(acc)vp[0], (acc)vp[1], (acc)vp[2]};
+  acc t[3];
   matvec3(t, R, v);
   out[0] = p[0] + t[0]; out[1] = p[1] + t[1]; out[2] = p[2] + t[2];
 }
-template <class real> NM_COLD void mpr_support(const Sh<real>& sh, const Model<real>& M, int g1, int g2, const real* dir, Sup<real>& s) {
-  real nd[3] = {-dir[0], -dir[1], -dir[2]};
-  hull_support(sh, M, g1, dir, s.v1);
-  hull_support(sh, M, g2, nd, s.v2);
+template <class acc, class real> NM_COLD void mpr_support(const Sh<real>& sh, const Model<real>& M, int g1, int g2, const acc* dir, Sup<acc>& s) {
+  acc nd[3] = {-dir[0], -dir[1], -dir[2]};
+  hull_support<acc>(sh, M, g1, dir, s.v1);
+  hull_support<acc>(sh, M, g2, nd, s.v2);
   s.v[0] = s.v1[0] - s.v2[0]; s.v[1] = s.v1[1] - s.v2[1]; s.v[2] = s.v1[2] - s.v2[2];
 }
 template <class real> NM_FN void sub3(real* r, const real* a, const real* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
@@ -781,24 +788,30 @@ template <class real> NM_FN real point_tri_dist2(const real* x0, const real* B, 
   return dist;
 }
 // true and (depth, dir from geom1 to geom2, pos) when the two hulls penetrate
-template <class real> NM_COLD bool mpr_penetration(const Sh<real>& sh, const Model<real>& M, int g1, int g2, real* depth, real* dir_out, real* pos) {
+template <class real_, class st> NM_COLD bool mpr_penetration(const Sh<st>& sh, const Model<st>& M, int g1, int g2, real_* depth, real_* dir_out, real_* pos) {
+  typedef real_ real;   // everything below computes in `real` (= acc); the env state is `st`
   Sup<real> p[4], v4;
   real dir[3], va[3], vb[3], dot;
+  const real mpr_tol = (real)M.mpr_tol;
   {  // discoverPortal: v0 = centre1 - centre2
-    const real *R1 = sh.colR + 9 * g1, *R2 = sh.colR + 9 * g2, *c1 = M.colc + kColN * g1, *c2 = M.colc + kColN * g2;
+    real R1[9], R2[9], c1[3], c2[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { R1[k] = (real)sh.colR[9 * g1 + k]; R2[k] = (real)sh.colR[9 * g2 + k]; }
+#pragma unroll
+    for (int k = 0; k < 3; k++) { c1[k] = (real)M.colc[kColN * g1 + k]; c2[k] = (real)M.colc[kColN * g2 + k]; }
     real t1[3], t2[3];
     matvec3(t1, R1, c1); matvec3(t2, R2, c2);
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-      p[0].v1[k] = sh.colp[3 * g1 + k] + t1[k];
-      p[0].v2[k] = sh.colp[3 * g2 + k] + t2[k];
+      p[0].v1[k] = (real)sh.colp[3 * g1 + k] + t1[k];
+      p[0].v2[k] = (real)sh.colp[3 * g2 + k] + t2[k];
       p[0].v[k] = p[0].v1[k] - p[0].v2[k];
     }
   }
   if (ccd_eq(p[0].v[0], real(0)) && ccd_eq(p[0].v[1], real(0)) && ccd_eq(p[0].v[2], real(0))) p[0].v[0] += ccd_eps<real>() * real(10);
   dir[0] = -p[0].v[0]; dir[1] = -p[0].v[1]; dir[2] = -p[0].v[2];
   ccd_normalize(dir);
-  mpr_support(sh, M, g1, g2, dir, p[1]);
+  mpr_support<real>(sh, M, g1, g2, dir, p[1]);
   dot = dot3<real>(p[1].v, dir);
   if (ccd_zero(dot) || dot < real(0)) return false;
   cross3(dir, p[0].v, p[1].v);
@@ -812,7 +825,7 @@ template <class real> NM_COLD bool mpr_penetration(const Sh<real>& sh, const Mod
     return true;
   }
   ccd_normalize(dir);
-  mpr_support(sh, M, g1, g2, dir, p[2]);
+  mpr_support<real>(sh, M, g1, g2, dir, p[2]);
   dot = dot3<real>(p[2].v, dir);
   if (ccd_zero(dot) || dot < real(0)) return false;
   sub3(va, p[1].v, p[0].v); sub3(vb, p[2].v, p[0].v);
@@ -824,7 +837,7 @@ template <class real> NM_COLD bool mpr_penetration(const Sh<real>& sh, const Mod
   }
   for (int size = 3, guard = 0; size < 4; guard++) {
     if (guard > 64) return false;
-    mpr_support(sh, M, g1, g2, dir, p[3]);
+    mpr_support<real>(sh, M, g1, g2, dir, p[3]);
     dot = dot3<real>(p[3].v, dir);
     if (ccd_zero(dot) || dot < real(0)) return false;
     bool cont = false;
@@ -847,15 +860,15 @@ template <class real> NM_COLD bool mpr_penetration(const Sh<real>& sh, const Mod
     dot = dot3<real>(dir, p[1].v);
     if (ccd_zero(dot) || dot > real(0)) break;
     if (guard > 100) return false;
-    mpr_support(sh, M, g1, g2, dir, v4);
+    mpr_support<real>(sh, M, g1, g2, dir, v4);
     dot = dot3<real>(v4.v, dir);
-    if (!(ccd_zero(dot) || dot > real(0)) || portal_reach_tol(p, v4, dir, M.mpr_tol)) return false;
+    if (!(ccd_zero(dot) || dot > real(0)) || portal_reach_tol(p, v4, dir, mpr_tol)) return false;
     expand_portal(p, v4);
   }
   for (int it = 0;; it++) {  // findPenetr
     portal_dir(p, dir);
-    mpr_support(sh, M, g1, g2, dir, v4);
-    if (portal_reach_tol(p, v4, dir, M.mpr_tol) || it > M.mpr_iters) {
+    mpr_support<real>(sh, M, g1, g2, dir, v4);
+    if (portal_reach_tol(p, v4, dir, mpr_tol) || it > M.mpr_iters) {
       real pd[3];
       *depth = vsqrt(point_tri_dist2(p[1].v, p[2].v, p[3].v, pd));
       if (ccd_zero(pd[0]) && ccd_zero(pd[1]) && ccd_zero(pd[2])) { pd[0] = dir[0]; pd[1] = dir[1]; pd[2] = dir[2]; }
@@ -949,13 +962,14 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
       real bound = k1[3] + k2[3];
       if (dot3<real>(dd, dd) > bound * bound) continue;
     }
-    real depth, dir[3], pos[3];
-    if (!mpr_penetration(sh, M, h1, h2, &depth, dir, pos)) continue;
-    if (!(depth > real(0))) continue;
+    typedef double acc;      // MPR computes in fp64 in both builds (see hull_support)
+    acc depth, dir[3], pos[3];
+    if (!mpr_penetration<acc>(sh, M, h1, h2, &depth, dir, pos)) continue;
+    if (!(depth > acc(0))) continue;
     if (ncon >= kMaxConBig) { *dropped += 1; continue; }   // cannot happen: see kMaxConBig
-    sh.cpos()[3 * ncon] = pos[0]; sh.cpos()[3 * ncon + 1] = pos[1]; sh.cpos()[3 * ncon + 2] = pos[2];
-    sh.cnrm()[3 * ncon] = dir[0]; sh.cnrm()[3 * ncon + 1] = dir[1]; sh.cnrm()[3 * ncon + 2] = dir[2];
-    sh.cdist()[ncon] = -depth;
+    sh.cpos()[3 * ncon] = (real)pos[0]; sh.cpos()[3 * ncon + 1] = (real)pos[1]; sh.cpos()[3 * ncon + 2] = (real)pos[2];
+    sh.cnrm()[3 * ncon] = (real)dir[0]; sh.cnrm()[3 * ncon + 1] = (real)dir[1]; sh.cnrm()[3 * ncon + 2] = (real)dir[2];
+    sh.cdist()[ncon] = (real)(-depth);
     sh.cleg()[ncon] = h2 - 1;
     sh.cleg1()[ncon] = h1 - 1;
     sh.anypair = 1;

@@ -15,6 +15,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/nightmare_hip.h"
@@ -29,6 +30,12 @@ constexpr int kMlpThreads = 512, kMlpWaves = kMlpThreads / 64;
 constexpr int kMaxSteps = kMaxDim / 4;            // k-steps of 4 per layer (one MFMA 16x16x4 each)
 constexpr int kQStride = kMaxSteps + 4;           // floats between the four (k mod 4) planes of a row: 16 B aligned, and the 16 columns a
                                                   // wave's epilogue stores per instruction land in 16 different banks (64 would put 4 in one)
+#ifndef NM_MLP_RING
+#define NM_MLP_RING 4
+#endif
+constexpr int kRing = NM_MLP_RING;                // weight fragment pairs in flight per wave (k-groups of 16 inputs, 2 KiB each); a power of two.
+                                                  // An L2 hit is back in 300-500 cycles (scripts/micro/stream_l2.hip), a group is 256 matrix-pipe cycles
+constexpr int kMaxGroups = kMaxDim / 16;          // k-groups per layer at most
 constexpr int kActLd = 4 * kQStride + 4;          // floats per activation row in LDS (16 B aligned; 8 consecutive rows cover all banks)
 
 struct MlpArgs {
@@ -54,6 +61,22 @@ __global__ void k_pack_weights(const float* __restrict__ W, f32x4* __restrict__ 
   P[i] = v;
 }
 
+// fragment `idx` (units of 16 bytes) of a wave-uniform array: the byte offset is formed in 32 bits, so the load can take the
+// `global_load_dwordx4 v, v_offset, s[base]` form (one VALU instruction per load) instead of a 64-bit per-lane address
+__device__ __forceinline__ f32x4 ldfrag(const f32x4* base, int idx) {
+  return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + (unsigned)(idx * 16));
+}
+
+// f(0) && f(1) && ... with compile-time indices: a fully unrolled loop whose `break` is a forward branch
+template <class F, int... I> __device__ __forceinline__ void unroll_while(std::integer_sequence<int, I...>, F&& f) {
+  (void)(f(std::integral_constant<int, I>{}) && ...);
+}
+
+// Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS traffic, then s_barrier. __syncthreads() also
+// drains the vector-memory queue (s_waitcnt vmcnt(0): a workgroup-scope release fence has to assume global memory), which would wait
+// for every weight fragment prefetched across the layer boundary before the barrier instead of underneath it.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 __device__ __forceinline__ int act_pos(int k) { return (k & 3) * kQStride + (k >> 2); }   // position of input k inside a row
 
 // what one wave does in one layer: a pair of 16-column tiles and a range of k-groups (narrow layers split K over the waves)
@@ -78,45 +101,85 @@ __device__ __forceinline__ WavePlan plan_layer(const MlpArgs& a, int l, int wave
   p.work = pr < npair;
   p.t0 = 2 * pr; p.t1 = min(2 * pr + 1, p.ntile - 1);
   p.two = 2 * pr + 1 < p.ntile;
-  p.w0 = a.w[l] + ((size_t)(p.work ? p.t0 : 0) * p.ngrp) * 64 + lane;
-  p.w1 = a.w[l] + ((size_t)(p.work ? p.t1 : 0) * p.ngrp) * 64 + lane;
+  // wave-uniform bases (SGPRs); the lane is added as a 32-bit offset at the access (global_load ... v_off, s[base])
+  p.w0 = a.w[l] + ((size_t)(p.work ? p.t0 : 0) * p.ngrp) * 64;
+  p.w1 = a.w[l] + ((size_t)(p.work ? p.t1 : 0) * p.ngrp) * 64;
   return p;
 }
 
+constexpr int kMaxWavesStamp = 8;
 #ifdef NM_MLP_STAMPS   // measurement build: cycle stamps of workgroup 0 (scripts/mlpstamps.py)
 __device__ unsigned long long g_mlp_stamps[16];
 #define MLP_STAMP(k) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_mlp_stamps[k] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_mlp_steps[4][kMaxWavesStamp][20];
+#define MLP_STEP(l, k) do { if (blockIdx.x == 0 && lane == 0 && (l) < 4) g_mlp_steps[l][wave][k] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int nm_mlp_read_steps(unsigned long long* out) {
+  (void)hipDeviceSynchronize();
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mlp_steps), sizeof(g_mlp_steps)) == hipSuccess ? 0 : 1;
+}
 extern "C" int nm_mlp_read_stamps(unsigned long long* out16) {
   (void)hipDeviceSynchronize();
   return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_mlp_stamps), sizeof(g_mlp_stamps)) == hipSuccess ? 0 : 1;
 }
 #else
 #define MLP_STAMP(k)
+#define MLP_STEP(l, k)
 #endif
 
 __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restrict__ obs, float* __restrict__ out, MlpArgs a) {
   __shared__ __attribute__((aligned(16))) float act[2][kTileRows * kActLd];
   __shared__ __attribute__((aligned(16))) float red[kMlpWaves][8][64];     // split-K partial accumulators of narrow layers
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  // the wave index as a scalar: everything planned from it (tile pair, k-range, weight base addresses, trip counts) is then
+  // wave-uniform to the compiler as well - scalar branches, SGPR base addresses - instead of "divergent" VGPR arithmetic
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 15, q = lane >> 4;
   const int row0 = blockIdx.x * kTileRows;
   MLP_STAMP(0);
-  // the first weights of layer 0 are in flight while the observation tile is staged (they do not depend on it)
+  // Weight stream: a ring of kRing fragment pairs per wave, filled kRing k-groups ahead of their use. Every ring slot is a fixed
+  // register (all indices below are compile-time after unrolling), so the compiler's s_waitcnt before a group's MFMAs waits for
+  // THAT group's two loads only (vmcnt = the loads issued since), not for everything in flight: the rotating-variable version of
+  // this loop (c <- n <- f by moves) compiled to `s_waitcnt vmcnt(0)` at the top of every iteration, i.e. a prefetch distance of ONE
+  // group = 256 matrix-pipe cycles against an L2 round trip of 500+ (wave active 20 %, matrix pipe busy 30 %).
+  f32x4 r0[kRing], r1[kRing];
+  // Every ring load is UNCONDITIONAL (a group that does not exist re-reads the wave's first fragment, a line that is hot in the
+  // CU's vector cache): only then is the number of loads issued between a fragment's load and its use a compile-time constant. With
+  // `if (group exists) load` the compiler has to assume the fewest, and waits with vmcnt(0) again.
+  auto fill = [&](const WavePlan& pl) {   // the first kRing groups of a layer: they depend on nothing but the plan, so they are issued
+#pragma unroll                            // before the observation is staged / before the previous layer's epilogue and barrier
+    for (int j = 0; j < kRing; j++) {
+      const int gj = pl.g0 + j < pl.g1 ? pl.g0 + j : pl.g0;
+      r0[j] = ldfrag(pl.w0, gj * 64 + lane); r1[j] = ldfrag(pl.w1, gj * 64 + lane);
+    }
+  };
   WavePlan p = plan_layer(a, 0, wave, lane);
-  f32x4 c0 = p.w0[(size_t)p.g0 * 64], c1 = p.w1[(size_t)p.g0 * 64];
-  f32x4 n0 = c0, n1 = c1;
-  if (p.g0 + 1 < p.g1) { n0 = p.w0[(size_t)(p.g0 + 1) * 64]; n1 = p.w1[(size_t)(p.g0 + 1) * 64]; }
   {  // stage the observation tile: wave w takes rows 2w and 2w+1 (coalesced), permuted to the [k mod 4][k div 4] layout; the
-     // k positions between K and the next multiple of 16 are zeroed (the packed weights are zero there, LDS garbage may be NaN)
+     // k positions between K and the next multiple of 16 are zeroed (the packed weights are zero there, LDS garbage may be NaN).
+     // The observation comes from HBM / the other XCDs' writes (>= 1 us) and is needed first: its loads go out BEFORE the weight ring
+     // (vector-memory loads return in order), the ring fill is issued underneath them.
     const int K = a.dims[0], Kp = (K + 15) & ~15;
+    float ov[2][kMaxDim / 64];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int rr = 2 * wave + h;
-      for (int kk = lane; kk < Kp; kk += 64)
-        act[0][rr * kActLd + act_pos(kk)] = (kk < K && row0 + rr < a.N) ? obs[(size_t)(row0 + rr) * K + kk] : 0.0f;
+#pragma unroll
+      for (int c = 0; c < kMaxDim / 64; c++) {
+        const int kk = lane + 64 * c;
+        ov[h][c] = (kk < K && row0 + rr < a.N) ? obs[(size_t)(row0 + rr) * K + kk] : 0.0f;
+      }
+    }
+    fill(p);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int rr = 2 * wave + h;
+#pragma unroll
+      for (int c = 0; c < kMaxDim / 64; c++) {
+        const int kk = lane + 64 * c;
+        if (kk < Kp) act[0][rr * kActLd + act_pos(kk)] = ov[h][c];
+      }
     }
   }
-  __syncthreads();
+  lds_barrier();
   MLP_STAMP(1);
   for (int l = 0; l < a.n_layers; l++) {
     const int O = a.dims[l + 1], Op = (O + 15) & ~15;
@@ -127,35 +190,63 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restri
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     // biases of this wave's two column tiles: requested now, needed in the epilogue
     const int bc0 = 16 * p.t0 + r, bc1 = 16 * p.t1 + r;
-    const float bias0 = (p.work && bc0 < O) ? B[bc0] : 0.0f, bias1 = (p.work && bc1 < O) ? B[bc1] : 0.0f;
-    if (p.work) {
-      f32x4 av = *reinterpret_cast<const f32x4*>(x + 4 * p.g0);
-      for (int gs = p.g0; gs < p.g1; gs++) {
-        f32x4 f0 = n0, f1 = n1;
-        if (gs + 2 < p.g1) { f0 = p.w0[(size_t)(gs + 2) * 64]; f1 = p.w1[(size_t)(gs + 2) * 64]; }   // weights: two groups ahead
-        const f32x4 an = *reinterpret_cast<const f32x4*>(x + 4 * min(gs + 1, p.g1 - 1));             // activations: one group ahead
+    // unconditional (index clamped; columns >= O are masked where they are stored): a conditional load compiles to `v = 0; if (..) v = load`,
+    // and the write of the 0 into a register that a load of the previous layer targeted costs an s_waitcnt vmcnt(0) at the loop head -
+    // i.e. a wait for the whole weight ring that was prefetched across the barrier
+    const float bias0 = B[min(bc0, O - 1)], bias1 = B[min(bc1, O - 1)];
+    // The layer as kRing-aligned steps: n real ones (8 MFMAs each), padded with MFMA-free steps to nv = 8 or 16. Every step refills the
+    // ring slot it has just consumed: with group i + kRing of this layer while there is one, then with the NEXT layer's groups - the
+    // padding makes next-layer group j land in slot j % kRing, where that layer's step j will look for it. So the first kRing groups
+    // of a layer are requested during the previous layer's last kRing steps, not after its MFMAs (where the first step then sat out
+    // an L2 round trip under load: ~2 us per layer boundary in the stamps), and the fill in front of layer 0 is the only other one.
+    WavePlan pn = p;
+    if (!last) pn = plan_layer(a, l + 1, wave, lane);
+    {
+      const int n = p.work ? p.g1 - p.g0 : 0;                    // k-groups of this wave in this layer: <= kMaxGroups
+      const int nv = last ? n : (n + kRing - 1 > kRing ? ((n + kRing - 1) & ~(kRing - 1)) : kRing);   // the last layer prefetches for nobody
+      const int nn = (!last && pn.work) ? pn.g1 - pn.g0 : 0;
+      f32x4 av = *reinterpret_cast<const f32x4*>(x + 4 * (n > 0 ? p.g0 : 0));
+      unroll_while(std::make_integer_sequence<int, kMaxGroups>{}, [&](auto iT) {
+        constexpr int i = decltype(iT)::value;
+        if (i >= nv) return false;                               // forward exits only: the chain of executed steps is straight-line code
+        if (i < n) {
+          const int gs = p.g0 + i;
+#ifdef NM_MLP_NOLDS
+          const f32x4 an = av;
+#else
+          const f32x4 an = *reinterpret_cast<const f32x4*>(x + 4 * min(gs + 1, p.g1 - 1));           // activations: one group ahead
+#endif
+          const f32x4 c0 = r0[i % kRing], c1 = r1[i % kRing];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c0[j], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c1[j], acc1, 0, 0, 0);
+          for (int j = 0; j < 4; j++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c0[j], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c1[j], acc1, 0, 0, 0);
+          }
+          av = an;
         }
-        c0 = n0; c1 = n1; n0 = f0; n1 = f1; av = an;
-      }
+#ifndef NM_MLP_NOLOAD
+        {  // refill (always two loads, see above); every choice below is wave-uniform
+          const int j = i + kRing - nv;                          // the next layer's group that belongs into this slot
+          const bool mine = i + kRing < n, next = !mine && j >= 0 && j < nn;
+          const f32x4* s0 = next ? pn.w0 : p.w0;
+          const f32x4* s1 = next ? pn.w1 : p.w1;
+          const int g = mine ? p.g0 + i + kRing : (next ? pn.g0 + j : 0);       // neither: the layer's first fragment, a hot line
+          r0[i % kRing] = ldfrag(s0, g * 64 + lane);
+          r1[i % kRing] = ldfrag(s1, g * 64 + lane);
+        }
+#endif
+        return true;
+      });
     }
     MLP_STAMP(2 + 3 * l);
     const WavePlan cur = p;
-    if (!last) {   // next layer's first weights: in flight across the epilogue and the barrier
-      p = plan_layer(a, l + 1, wave, lane);
-      c0 = p.w0[(size_t)p.g0 * 64]; c1 = p.w1[(size_t)p.g0 * 64];
-      n0 = c0; n1 = c1;
-      if (p.g0 + 1 < p.g1) { n0 = p.w0[(size_t)(p.g0 + 1) * 64]; n1 = p.w1[(size_t)(p.g0 + 1) * 64]; }
-    }
+    p = pn;
     if (cur.split > 1) {   // reduce the k-parts: both accumulators parked at once, the first wave of a pair adds them up
       if (cur.work && cur.part != 0) {
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) { red[wave][reg][lane] = acc0[reg]; red[wave][4 + reg][lane] = acc1[reg]; }
       }
-      __syncthreads();
+      lds_barrier();
       if (cur.work && cur.part == 0) {
         for (int pp = 1; pp < cur.split; pp++)
 #pragma unroll
@@ -184,7 +275,7 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restri
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     MLP_STAMP(4 + 3 * l);
   }
 }

@@ -64,6 +64,7 @@ NM_FN double vpow(double x, double p) { return pow(x, p); }
 NM_FN bool visbad(float x) { return !(fabsf(x) <= 1e10f); }
 NM_FN bool visbad(double x) { return !(fabs(x) <= 1e10); }
 template <class T> NM_FN T to_real(int i) { return (T)i; }
+template <class T, class S> NM_FN T vcvt(S x) { return (T)x; }   // per-lane value conversion (fp32 state -> fp64 MPR arithmetic)
 
 // value of lane l (l wave-uniform) as a wave-uniform scalar
 NM_FN int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
@@ -244,6 +245,7 @@ NM_FN bool visbad(float x) { return !(std::fabs(x) <= 1e10f); }
 NM_FN bool visbad(double x) { return !(std::fabs(x) <= 1e10); }
 template <class T> NM_FN V<T> to_real(const V<int>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)a.v[i]; return r; }
 template <class T> NM_FN T to_real(int a) { return (T)a; }
+template <class T, class S> NM_FN V<T> vcvt(const V<S>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)a.v[i]; return r; }
 
 template <class T> NM_FN T rdlane(const V<T>& x, int l) { return x.v[l]; }
 template <class T> NM_FN T rdlane(T x, int) { return x; }
