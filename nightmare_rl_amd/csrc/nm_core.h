@@ -242,13 +242,13 @@ template <class X, class real> NM_FN void spatial_inertia(X* I10, const X* R, co
 // leaf (tibia) first as mj_factorM does: backward stable on these graded blocks (the cofactor inverse is not
 // and costs fp32 three digits). Factor = (l21 l20 l10 1/d2 1/d1 1/d0).
 template <class X, class real> NM_FN void ldl3(X* r, const X* a, real one) {
-  X i2 = X(one) / a[5];
+  X i2 = vrcp(a[5]);
   X l21 = a[4] * i2, l20 = a[2] * i2;
   X m11 = a[3] - l21 * a[4], m01 = a[1] - l21 * a[2], m00 = a[0] - l20 * a[2];
-  X i1 = X(one) / m11;
+  X i1 = vrcp(m11);
   X l10 = m01 * i1;
   X d0 = m00 - l10 * m01;
-  r[0] = l21; r[1] = l20; r[2] = l10; r[3] = i2; r[4] = i1; r[5] = X(one) / d0;
+  r[0] = l21; r[1] = l20; r[2] = l10; r[3] = i2; r[4] = i1; r[5] = vrcp(d0);
 }
 template <class X, class Y> NM_FN void ldl3_solve(X* x, const X* f, const Y* y) {
   X y2 = y[2];
@@ -269,7 +269,7 @@ template <class X, class real, class Acc> NM_FN void ldl6(Acc S, X* L, X* Dinv, 
 #pragma unroll
     for (int k = 0; k < j; k++) d = d - Lf[6 * j + k] * Lf[6 * j + k] * D[k];
     D[j] = d;
-    X di = X(one) / d;
+    X di = vrcp(d);
     Dinv[j] = di;
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
@@ -1294,12 +1294,12 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
   vr imp;
   {
-    vr x = vabs(dist) / M.si_width;
+    vr x = vabs(dist) * vrcp(M.si_width);
     vr ylo, yhi;
     if (M.si_power == real(2)) {  // the model's solimp (mjmodel.xml defaults): pow(x, 2) = x*x and pow(mid, 1) = mid, both exact
       vr omx = vmax(vr(real(1)) - x, vr(real(0)));
-      ylo = (x * x) / M.si_mid;
-      yhi = vr(real(1)) - (omx * omx) / (real(1) - M.si_mid);
+      ylo = (x * x) * vrcp(M.si_mid);
+      yhi = vr(real(1)) - (omx * omx) * vrcp(real(1) - M.si_mid);
     } else {
       ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
       yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
@@ -1311,8 +1311,8 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   }
   vr invw = ldsv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
   if (anypair) invw = invw + sel(onleg1, ldsv(M.colc, (Lc1 + 1) * kColN + 4), vr(real(0)));
-  vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
-  vr Dd = vr(real(1)) / Rr;
+  vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) * vrcp(imp), vr(real(1e-15))) * (real(2) * M.mu * M.mu);
+  vr Dd = vrcp(Rr);
   // sparse dots with the wave-uniform vectors qvel, qacc_smooth, qacc_warmstart
   vr vel = vr(real(0)), jas = vr(real(0)), jaw = vr(real(0));
 #pragma unroll
@@ -1399,7 +1399,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   vr Ajj = u[0] * xb[0] + u[1] * xb[1] + u[2] * xb[2] + u[3] * xb[3] + u[4] * xb[4] + u[5] * xb[5] + (Jl[0] * t[0] + Jl[1] * t[1] + Jl[2] * t[2]);
   if (anypair) Ajj += Jm[0] * t1m[0] + Jm[1] * t1m[1] + Jm[2] * t1m[2];   // the two bodies of a pair are different legs
   vr ARjj = Ajj + Rr;
-  vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
+  vr ARinv = sel(act, vrcp(ARjj), vr(real(0)));
 
   nm_stamp(5);
   // ---- warm start (PGS branch of mj_fwdConstraint): f from qacc_warmstart, kept only if its dual cost < 0
@@ -1468,7 +1468,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     Amq = sel(even, Amq, shfl_xor1(Amq));
     const vr K1 = Ajj + shfl_xor1(Ajj) - Amq - Amq;
     const VB small = K1 < vr(real(1e-15));       // degenerate pair: both forces go to their mean
-    const vr invK1 = vr(real(1)) / K1, hK1 = real(0.5) * K1;
+    const vr invK1 = vrcp(K1), hK1 = real(0.5) * K1;
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       real improvement = real(0);
       if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
@@ -1674,12 +1674,12 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   // impedance, regulariser, reference acceleration (mj_makeImpedance / mj_referenceConstraint)
   vr imp;
   {
-    vr x = vabs(dist) / M.si_width;
+    vr x = vabs(dist) * vrcp(M.si_width);
     vr ylo, yhi;
     if (M.si_power == real(2)) {
       vr omx = vmax(vr(real(1)) - x, vr(real(0)));
-      ylo = (x * x) / M.si_mid;
-      yhi = vr(real(1)) - (omx * omx) / (real(1) - M.si_mid);
+      ylo = (x * x) * vrcp(M.si_mid);
+      yhi = vr(real(1)) - (omx * omx) * vrcp(real(1) - M.si_mid);
     } else {
       ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
       yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
@@ -1690,8 +1690,8 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
     imp = sel(x <= vr(real(0)), vr(M.si_d0), imp);
   }
   vr invw = ldsv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
-  vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
-  vr Dd = vr(real(1)) / Rr;
+  vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) * vrcp(imp), vr(real(1e-15))) * (real(2) * M.mu * M.mu);
+  vr Dd = vrcp(Rr);
   vr vel = vr(real(0)), jas = vr(real(0)), jaw = vr(real(0));
 #pragma unroll
   for (int j = 0; j < 6; j++) {
@@ -1752,7 +1752,7 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
 #undef NM_BUILD4
   vr Ajj = u[0] * xb[0] + u[1] * xb[1] + u[2] * xb[2] + u[3] * xb[3] + u[4] * xb[4] + u[5] * xb[5] + (Jl[0] * t[0] + Jl[1] * t[1] + Jl[2] * t[2]);
   vr ARjj = Ajj + Rr;
-  vr ARinv = sel(act, vr(real(1)) / ARjj, vr(real(0)));
+  vr ARinv = sel(act, vrcp(ARjj), vr(real(0)));
 
   nm_stamp(5);
   // ---- warm start
@@ -1813,7 +1813,7 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
     Amq = sel(even, Amq, shfl_xor1(Amq));
     const vr K1 = Ajj + shfl_xor1(Ajj) - Amq - Amq;
     const VB small = K1 < vr(real(1e-15));
-    const vr invK1 = vr(real(1)) / K1, hK1 = real(0.5) * K1;
+    const vr invK1 = vrcp(K1), hK1 = real(0.5) * K1;
     VB run = VB(true);
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       vr improvement = vr(real(0));
@@ -2079,12 +2079,12 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
     }
     vr imp;
     {
-      vr x = vabs(dist) / M.si_width;
+      vr x = vabs(dist) * vrcp(M.si_width);
       vr ylo, yhi;
       if (M.si_power == real(2)) {
         vr omx = vmax(vr(real(1)) - x, vr(real(0)));
-        ylo = (x * x) / M.si_mid;
-        yhi = vr(real(1)) - (omx * omx) / (real(1) - M.si_mid);
+        ylo = (x * x) * vrcp(M.si_mid);
+        yhi = vr(real(1)) - (omx * omx) * vrcp(real(1) - M.si_mid);
       } else {
         ylo = vpow(x, vr(M.si_power)) / vpow(vr(M.si_mid), vr(M.si_power - real(1)));
         yhi = vr(real(1)) - vpow(vmax(vr(real(1)) - x, vr(real(0))), vr(M.si_power)) / vpow(vr(real(1) - M.si_mid), vr(M.si_power - real(1)));
@@ -2096,7 +2096,7 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
     }
     vr invw = ldsv(M.colc, (Lc + sel(onleg, V<int>(1), V<int>(0))) * kColN + 4);
     invw = invw + sel(onleg1, ldsv(M.colc, (Lc1 + 1) * kColN + 4), vr(real(0)));
-    const vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) / imp, vr(real(1e-15))) * (real(2) * M.mu * M.mu);
+    const vr Rr = vmax((vr(real(1)) - imp) * (invw + M.mu * M.mu * invw) * vrcp(imp), vr(real(1e-15))) * (real(2) * M.mu * M.mu);
     vr vel = vr(real(0)), jas = vr(real(0)), jaw = vr(real(0));
 #pragma unroll
     for (int j = 0; j < 6; j++) {
@@ -2129,16 +2129,16 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
     Apq = sel(even, Apq, shfl_xor1(Apq));   // the even row's copy of A[2p][2p+1] in both lanes of the pair
     const vr K1 = Ajj + shfl_xor1(Ajj) - Apq - Apq;
     r.small[k] = K1 < vr(real(1e-15));
-    r.invK1[k] = vr(real(1)) / K1;
+    r.invK1[k] = vrcp(K1);
     r.hK1[k] = real(0.5) * K1;
     const vr ARjj = Ajj + Rr;
-    r.ARinv[k] = sel(act, vr(real(1)) / ARjj, vr(real(0)));
+    r.ARinv[k] = sel(act, vrcp(ARjj), vr(real(0)));
     r.hA[k] = real(0.5) * ARjj;
     r.Rr[k] = Rr;
     r.bb[k] = jas - aref;
     r.L[k] = L; r.L1[k] = L1; r.act[k] = act;
     const vr jar = jaw - aref;   // warm start (PGS branch of mj_fwdConstraint)
-    r.f[k] = sel(act & (jar < vr(real(0))), -(vr(real(1)) / Rr) * jar, vr(real(0)));
+    r.f[k] = sel(act & (jar < vr(real(0))), -vrcp(Rr) * jar, vr(real(0)));
   }
   // ---- warm start: keep f only if its dual cost is below that of zero
   {
@@ -2351,14 +2351,15 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
     vr ang = M.h * n, sn, cs;
     vsincos(real(0.5) * ang, &sn, &cs);
     rot = rot & (ang != vr(real(0)));
-    vr qr[4] = {sel(rot, cs, vr(real(1))), sel(rot, nv[3] / ns * sn, vr(real(0))), sel(rot, nv[4] / ns * sn, vr(real(0))),
-                sel(rot, nv[5] / ns * sn, vr(real(0)))};
+    const vr isn = vrcp(ns) * sn;
+    vr qr[4] = {sel(rot, cs, vr(real(1))), sel(rot, nv[3] * isn, vr(real(0))), sel(rot, nv[4] * isn, vr(real(0))),
+                sel(rot, nv[5] * isn, vr(real(0)))};
     vr a[4] = {LDG(qpos, 3), LDG(qpos, 4), LDG(qpos, 5), LDG(qpos, 6)};
     vr t[4] = {a[0] * qr[0] - a[1] * qr[1] - a[2] * qr[2] - a[3] * qr[3], a[0] * qr[1] + a[1] * qr[0] + a[2] * qr[3] - a[3] * qr[2],
                a[0] * qr[2] - a[1] * qr[3] + a[2] * qr[0] + a[3] * qr[1], a[0] * qr[3] + a[1] * qr[2] - a[2] * qr[1] + a[3] * qr[0]};
     vr nn = vsqrt(t[0] * t[0] + t[1] * t[1] + t[2] * t[2] + t[3] * t[3]);  // mj_kinematics normalises before use
 #pragma unroll
-    for (int j = 0; j < 4; j++) nq[j] = t[j] / nn;
+    for (int j = 0; j < 4; j++) nq[j] = t[j] * vrcp(nn);
   }
   vr jq[3], jv[3];
 #pragma unroll
@@ -2412,6 +2413,25 @@ template <class real> NM_FN void reset_data(Sh<real>& sh, const Model<real>& M) 
   wave_sync();
 }
 
+// Critical-path scheduling between the two waves that share a SIMD for the whole launch (4096 envs = exactly 2 waves per SIMD, one
+// round): the launch ends with its slowest wave, and what makes a wave slow is known as soon as its collision stage has run - the
+// contact count (3.9 k cycles per contact, profiles/r02_wavetimes.txt). A wave with many contacts raises its issue priority, so that
+// where both waves of the SIMD have an instruction ready the one on the critical path goes first; its lighter partner has the slack.
+// Measured (MI355X, 4096 envs): 75.0 -> 72.5 us; the wave-lifetime regression's per-contact cost 3.8 k -> 2.2 k cycles, p99 158 k -> 150 k.
+#ifndef NM_PRIO
+#define NM_PRIO 3      /* contacts (both envs of the wave) from which the priority starts to rise; a large value switches it off */
+#endif
+#if !defined(NM_EMUL)
+NM_FN void nm_set_priority(int load) {
+  if (load >= NM_PRIO + 4) __builtin_amdgcn_s_setprio(3);
+  else if (load >= NM_PRIO + 2) __builtin_amdgcn_s_setprio(2);
+  else if (load >= NM_PRIO) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+#else
+inline void nm_set_priority(int) {}
+#endif
+
 // mj_step(model, data, 1) for the G envs of the wave
 template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<real>& M, bool last, int* dropped, int ablate) {
   const V<int> lane = opaque_lane();
@@ -2435,7 +2455,7 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
       const V<real> n = vsqrt(q3 * q3 + q4 * q4 + q5 * q5 + q6 * q6);
       const V<real> mine = sel(hl == 3, q3, sel(hl == 4, q4, sel(hl == 5, q5, q6)));
       wave_sync();
-      stsv(rbw, ho + (hl + NM_OFS(qpos)), mine / n, (hl >= 3) & (hl <= 6));
+      stsv(rbw, ho + (hl + NM_OFS(qpos)), mine * vrcp(n), (hl >= 3) & (hl <= 6));
     }
   } else {
     for (int e = 0; e < G; e++) {
@@ -2447,7 +2467,8 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
       }
       {  // mj_kinematics normalises the free joint's quaternion in qpos
         real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
-        real a = sh.qpos[3] / n, b = sh.qpos[4] / n, c = sh.qpos[5] / n, d = sh.qpos[6] / n;
+        const real in_ = vrcp(n);
+        real a = sh.qpos[3] * in_, b = sh.qpos[4] * in_, c = sh.qpos[5] * in_, d = sh.qpos[6] * in_;
         wave_sync();
         sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
       }
@@ -2467,6 +2488,7 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
   bool together = false;
   if constexpr (G == 2) {
     const int n0 = uniform(w.e[0].ncon), n1 = uniform(w.e[1].ncon);
+    nm_set_priority(n0 + n1);
     together = n0 >= 1 && n1 >= 1 && n0 <= kMaxCon2 && n1 <= kMaxCon2 && uniform(w.e[0].anypair) == 0 && uniform(w.e[1].anypair) == 0 && !(ablate & 32);
     if (together) {
 #ifdef NM_EMUL
@@ -2515,7 +2537,7 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   stsv(sh.qpos, lane, q_in, lane < kNQ);
   stsv(sh.qvel, lane, v_in, lane < kNV);
   stsv(sh.warm, lane, w_in, lane < kNV);
-  stsv(sh.hcache, lane, hc_in, lane < 8);
+  stsv(sh.hcache, lane, sel(lane == 0, hc_in & V<int>(0xffff), hc_in), lane < 8);     // bits 16.. of [0]: load hint of the two-env build
   sh.nwarn = 0;
   sh.nhop = 0;
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
@@ -2875,7 +2897,10 @@ template <class real> NM_FN void env_load2(ShW<real, 2>& w, const Model<real>& M
   stsv(rb, ho + (hl + NM_OFS(qpos)), q_in, hl < kNQ);
   stsv(rb, ho + (hl + NM_OFS(qvel)), v_in, hl < kNV);
   stsv(rb, ho + (hl + NM_OFS(warm)), w_in, hl < kNV);
-  stsv(ib, hoi + (hl + NM_IOFS(hcache)), hc_in, hl < 8);
+  // hullcache[0] carries, above bit 16, the env's contact count at the end of the previous step (see env_finish2): the wave's issue
+  // priority from its first instruction on (contact counts of consecutive steps correlate), refined after every collision stage
+  stsv(ib, hoi + (hl + NM_IOFS(hcache)), sel(hl == 0, hc_in & V<int>(0xffff), hc_in), hl < 8);
+  nm_set_priority((rdlane(hc_in, 0) >> 16) + (rdlane(hc_in, 32) >> 16));
   w.e[0].nwarn = 0; w.e[1].nwarn = 0;
   w.e[0].nhop = 0; w.e[1].nhop = 0;
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
@@ -2943,7 +2968,8 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
   // ---- store physics state
   const V<int> nwarn = SHI(nwarn, V<int>(0));
   {
-    const V<int> hc = SHI(hcache, sel(hl < 8, hl, V<int>(0)));
+    V<int> hc = SHI(hcache, sel(hl < 8, hl, V<int>(0)));
+    hc = sel(hl == 0, hc | (SHI(ncon, V<int>(0)) << 16), hc);     // the load hint for the next step
     const vr q = SHR(qpos, sel(hl < kNQ, hl, V<int>(0))), v = SHR(qvel, sel(hl < kNV, hl, V<int>(0))), wq = SHR(warm, sel(hl < kNV, hl, V<int>(0)));
     gstv(A.hullcache, hl + env * 8, hc, live & (hl < 8));
     gstv(A.qpos, hl + env * kNQ, q, live & (hl < kNQ));

@@ -65,6 +65,11 @@ NM_FN bool visbad(float x) { return !(fabsf(x) <= 1e10f); }
 NM_FN bool visbad(double x) { return !(fabs(x) <= 1e10); }
 template <class T> NM_FN T to_real(int i) { return (T)i; }
 template <class T, class S> NM_FN T vcvt(S x) { return (T)x; }   // per-lane value conversion (fp32 state -> fp64 MPR arithmetic)
+// 1 / x. fp32: v_rcp_f32 (1 ulp) - the operands here (pivots of positive definite blocks, norms, impedances) are far from the
+// denormal range, which is all that the compiler's division sequence (2.5 ulp + frexp / ldexp range scaling, ~8 instructions) adds;
+// ~90 divisions per wave and step. The fp64 verification build divides exactly.
+NM_FN float vrcp(float x) { return __builtin_amdgcn_rcpf(x); }
+NM_FN double vrcp(double x) { return 1.0 / x; }
 
 // value of lane l (l wave-uniform) as a wave-uniform scalar
 NM_FN int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
@@ -245,6 +250,9 @@ NM_FN bool visbad(float x) { return !(std::fabs(x) <= 1e10f); }
 NM_FN bool visbad(double x) { return !(std::fabs(x) <= 1e10); }
 template <class T> NM_FN V<T> to_real(const V<int>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)a.v[i]; return r; }
 template <class T> NM_FN T to_real(int a) { return (T)a; }
+template <class T> NM_FN V<T> vrcp(const V<T>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)1 / a.v[i]; return r; }
+NM_FN float vrcp(float x) { return 1.0f / x; }
+NM_FN double vrcp(double x) { return 1.0 / x; }
 template <class T, class S> NM_FN V<T> vcvt(const V<S>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)a.v[i]; return r; }
 
 template <class T> NM_FN T rdlane(const V<T>& x, int l) { return x.v[l]; }

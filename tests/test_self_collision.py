@@ -98,6 +98,6 @@ def test_device_code_fp64_matches_oracle_with_leg_contacts(oracle_mod):
 
 
 def test_device_code_fp32_within_tolerance_with_leg_contacts(oracle_mod):
-    oerr, serr, ncontact = run_pairwise(EmulDev, oracle_mod, double=False)
-    assert ncontact >= 10
-    assert np.median(oerr) < 5e-6 and np.percentile(oerr, 90) < 1e-4, (np.median(oerr), np.percentile(oerr, 90), oerr.max())
+    oerr, serr, ncontact = run_pairwise(EmulDev, oracle_mod, double=False, steps=12, n=48)
+    assert ncontact >= 40
+    assert oerr.max() <= 1e-4 and np.median(oerr) < 5e-6, (np.median(oerr), oerr.max())      # no allowance: MPR runs in fp64 in both builds
