@@ -378,11 +378,19 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
   real* lds = reinterpret_cast<real*>(&w.e[0]);
   const Grp<real, G> gp;
   const V<int> leg = gp.leg, eo = gp.eo;
-  const VB isleg = gp.isleg, lead = gp.lead;
+  const VB isleg = gp.sub < V<int>(6);   // NOT `& gact`: the lane groups beyond G must compute env G-1 again, exactly (see the stores below)
 #define LDG(field, i) ldsv(lds, eo + (NM_OFS(field) + (i)))
-#define STG(field, i, val) stsv(lds, eo + (NM_OFS(field) + (i)), val, lead)
+  // Stores of this stage are NOT masked: the lanes outside `isleg` / `lead` hold exact duplicates (sub 6, 7 compute leg 5 again, the
+  // lane groups beyond G alias env G-1, per-env values are computed by all eight lanes of a group), so they write the same value to
+  // the same address. A masked store is an exec-mask branch: 70 of them cut this stage into ~45-instruction scheduling regions.
+#ifdef NM_MASKED_A     // A/B only
+  const VB st_all = gp.lead, st_leg = gp.isleg;
+#else
+  const VB st_all = VB(true), st_leg = VB(true);
+#endif
+#define STG(field, i, val) stsv(lds, eo + (NM_OFS(field) + (i)), val, st_all)
 #define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
-#define STL(field, idx, val) stsv(lds, eo + (idx) + NM_OFS(field), val, isleg)
+#define STL(field, idx, val) stsv(lds, eo + (idx) + NM_OFS(field), val, st_leg)
   const V<int> slot = leg * (3 * kLinkTmp);
 
   // ---- base frame (per env)
@@ -615,11 +623,11 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
     const int oMinv = pass ? NM_OFS(MinvH) : NM_OFS(Minv), oW = pass ? NM_OFS(WH) : NM_OFS(W);
     const int oL = pass ? NM_OFS(LbH) : NM_OFS(Lb), oD = pass ? NM_OFS(DbiH) : NM_OFS(Dbi);
 #pragma unroll
-    for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 6 + (oMinv + j), Mi[j], isleg);
+    for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 6 + (oMinv + j), Mi[j], st_leg);
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
-      for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 18 + (oW + 6 * k + j), W[k][j], isleg);
+      for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 18 + (oW + 6 * k + j), W[k][j], st_leg);
     // Schur complement of the leg blocks (upper triangle, row-major in LDS)
 #pragma unroll
     for (int i = 0; i < 6; i++)
@@ -632,9 +640,9 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
     vr L[15], Di[6];
     ldl6([&](int r, int c) { return LDG(sc, 6 * r + c); }, L, Di, real(1));
 #pragma unroll
-    for (int j = 0; j < 15; j++) stsv(lds, eo + (oL + j), L[j], lead);
+    for (int j = 0; j < 15; j++) stsv(lds, eo + (oL + j), L[j], st_all);
 #pragma unroll
-    for (int j = 0; j < 6; j++) stsv(lds, eo + (oD + j), Di[j], lead);
+    for (int j = 0; j < 6; j++) stsv(lds, eo + (oD + j), Di[j], st_all);
     if (pass == 0) {
       // ---- servo forces, qfrc_smooth, qacc_smooth = M^-1 qfrc_smooth (block solve in the leg layout)
       vr y[3], t[3];
