@@ -161,6 +161,7 @@ template <class real> struct Sh {
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
   unsigned ectr;                  // command RNG counter
   int cstart[8], ccnt[8];         // contacts of colliding mesh g (0 = base, 1..6 = tibias): first index and count (floor contacts)
+  real sink[NM_WAVE];             // scratch row for branch-free masked stores (stsu): one word per lane, never read
   int hcache[8];                  // [0..6] support vertex of each colliding mesh found last time (warm start of the hull search);
                                   // [7] running count of this env's exhaustive-scan fallbacks (a tuning diagnostic that travels with the
                                   // row: 2048 waves adding to ONE counter serialise at ~12 ns each and hold the kernel's end back)
@@ -1132,15 +1133,15 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       const VB wr = (self | (ok & (rank < 3))) & (slot < kMaxConBig);
       const V<int> sl = sel(wr, slot, V<int>(0));
       const vr cd = sel(self, vr(dist), pnt[2] + bz);
-      stsv(sh.cpos(), sl * 3, pnt[0], wr);
-      stsv(sh.cpos(), sl * 3 + 1, pnt[1], wr);
-      stsv(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr);
-      stsv(sh.cdist(), sl, cd, wr);
-      stsv(sh.cleg(), sl, g - 1, wr);
-      stsv(sh.cleg1(), sl, -1, wr);
-      stsv(sh.cnrm(), sl * 3, real(0), wr);
-      stsv(sh.cnrm(), sl * 3 + 1, real(0), wr);
-      stsv(sh.cnrm(), sl * 3 + 2, real(1), wr);
+      stsu(sh.cpos(), sl * 3, pnt[0], wr, sh.sink);
+      stsu(sh.cpos(), sl * 3 + 1, pnt[1], wr, sh.sink);
+      stsu(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr, sh.sink);
+      stsu(sh.cdist(), sl, cd, wr, sh.sink);
+      stsu(sh.cleg(), sl, V<int>(g - 1), wr, sh.sink);
+      stsu(sh.cleg1(), sl, V<int>(-1), wr, sh.sink);
+      stsu(sh.cnrm(), sl * 3, vr(real(0)), wr, sh.sink);
+      stsu(sh.cnrm(), sl * 3 + 1, vr(real(0)), wr, sh.sink);
+      stsu(sh.cnrm(), sl * 3 + 2, vr(real(1)), wr, sh.sink);
     }
     const int ng = hitg ? 1 + nextra : 0;
     const int c0 = vmin(total, kMaxConBig), c1 = vmin(total + ng, kMaxConBig);
@@ -1893,8 +1894,8 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
     const VB lead = act & ((hl & 3) == 0);
     wave_sync();
 #pragma unroll
-    for (int k = 0; k < 3; k++) stsv(jrow, jh + (c * 8 + k), s3[k], lead);
-    if (last) { stsv(jrow, jh + (c * 8 + 3), tn, lead); stsv(jrow, jh + (c * 8 + 4), tf, lead); }
+    for (int k = 0; k < 3; k++) stsu(jrow, jh + (c * 8 + k), s3[k], lead, w.e[0].sink);
+    if (last) { stsu(jrow, jh + (c * 8 + 3), tn, lead, w.e[0].sink); stsu(jrow, jh + (c * 8 + 4), tf, lead, w.e[0].sink); }
     wave_sync();
     const VB on = hl < 30;
     const V<int> lg = sel(on, (hl * 13) >> 6, V<int>(0)), qq = hl - lg * 5;
@@ -1905,10 +1906,10 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
       VB in = on & (cn > k);
       acc = acc + sel(in, ldsv(jrow, jh + sel(in, (c0 + k) * 8 + qq, V<int>(0))), vr(real(0)));
     }
-    stsv(rbw, ho + (lg * 3 + qq + (6 + NM_OFS(qfc))), acc, on & (qq < 3));
+    stsu(rbw, ho + (lg * 3 + qq + (6 + NM_OFS(qfc))), acc, on & (qq < 3), w.e[0].sink);
     if (last) {
-      stsv(rbw, ho + (lg + NM_OFS(sens)), acc, on & (qq == 3));          // tibia sites: 10 m spheres see every contact of the body
-      stsv(rbw, ho + (lg + (6 + NM_OFS(sens))), acc, on & (qq == 4));    // foot sites
+      stsu(rbw, ho + (lg + NM_OFS(sens)), acc, on & (qq == 3), w.e[0].sink);          // tibia sites: 10 m spheres see every contact of the body
+      stsu(rbw, ho + (lg + (6 + NM_OFS(sens))), acc, on & (qq == 4), w.e[0].sink);    // foot sites
       stsv(rbw, ho + V<int>(12 + NM_OFS(sens)), hsum32(sel(act & ((hl & 3) == 0) & (L < 0), tn, vr(real(0)))), VB(true));
     }
   }

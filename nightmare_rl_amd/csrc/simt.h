@@ -167,6 +167,12 @@ template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
 }
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; }
+// masked LDS store without a branch: lanes outside the mask write their value to their own word of a scratch row instead. A masked
+// store compiles to s_and_saveexec / s_cbranch_execz / ds_write / s_or - the end of a scheduling region; this is one v_cndmask on the address.
+template <class T, class S> NM_FN void stsu(T* a, int i, T v, bool m, S* sink) {
+  T* p = m ? a + i : reinterpret_cast<T*>(sink) + threadIdx.x;
+  *p = v;
+}
 // Global-memory accessors. The pointers reach the kernel through an LDS copy of the launch arguments / model struct, so
 // the compiler no longer knows their address space: the casts keep these global_load / global_store instead of flat_*.
 #define NM_GLOBAL(T) __attribute__((address_space(1))) T
@@ -299,6 +305,8 @@ template <class T> NM_FN V<T> ldsv(const T* a, const V<int>& i) { V<T> r; for (i
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, const V<int>& i, const V<T>& v, const VB& m) { for (int k = 0; k < NM_WAVE; k++) if (m.v[k]) a[i.v[k]] = v.v[k]; }
 template <class T> NM_FN void stsv(T* a, const V<int>& i, T v, const VB& m) { for (int k = 0; k < NM_WAVE; k++) if (m.v[k]) a[i.v[k]] = v; }
+template <class T, class S> NM_FN void stsu(T* a, const V<int>& i, const V<T>& v, const VB& m, S*) { stsv(a, i, v, m); }
+template <class T, class S> NM_FN void stsu(T* a, const V<int>& i, T v, const VB& m, S*) { stsv(a, i, v, m); }
 template <class T> NM_FN T gld1(const T* p, size_t i) { return p[i]; }
 template <class T> NM_FN void gst1(T* p, size_t i, T v) { p[i] = v; }
 template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p, i); }
