@@ -36,3 +36,6 @@ for rep in range(3):
     res = life - X @ coef
     print("   lifetime ~ %.0f + %.0f*ncon(last substep, both envs) + %.0f*fallbacks + %.0f*hops + %.0f*noslip_iters + %.0f*pairflag ; residual std %.0f" % (*coef, res.std()))
     print("   means: ncon %.2f fallbacks %.2f hops %.2f noslip iters %.2f pair %.3f" % (ncon.sum(1).mean(), fb.mean(), hop.mean(), nos.mean(), pair.mean()))
+    print("   slowest 12 waves: (lifetime, ncon e0+e1, hops, fallbacks, residual):",
+          [(int(life[i]), int(ncon[i].sum()), int(hop[i]), int(fb[i]), int(res[i])) for i in slow[:12]])
+    print("   hops p50/p90/p99/max %s ; ncon sum p50/p90/p99/max %s" % (np.percentile(hop, [50, 90, 99, 100]).tolist(), np.percentile(ncon.sum(1), [50, 90, 99, 100]).tolist()))
