@@ -2872,7 +2872,10 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 // env_load / env_finish, executed once instead of twice: per-env scalars become per-lane values that are equal inside a half,
 // LDS addresses carry the half's image offset, sums over joints are half-wave sums (hsum32). What is genuinely scalar (episode
 // length as int64, the command RNG) stays scalar, once per half. Every HBM read of BOTH envs is in flight before the first wait.
-template <class real> NM_FN void env_load2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave) {
+// `mid()` runs after every HBM read has been issued and before the first of them is waited for: the kernel copies the model constants
+// (L2 -> LDS, `M` is that copy) there, so the two round trips of a wave's start-up overlap instead of following each other.
+struct NoMid { NM_FN void operator()() const {} };
+template <class real, class Mid> NM_FN void env_load2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave, Mid&& mid) {
   typedef V<real> vr;
   constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real)), kSI = (int)(sizeof(Sh<real>) / sizeof(int));
   const V<int> lane = opaque_lane();
@@ -2905,6 +2908,7 @@ template <class real> NM_FN void env_load2(ShW<real, 2>& w, const Model<real>& M
     prev_dofvel = gldv(A.dofvel, l18c + env * kNU);
     dofpos_old = gldv(A.dofpos, l18c + env * kNU);
   }
+  mid();
   stsv(rb, ho + (hl + NM_OFS(qpos)), q_in, hl < kNQ);
   stsv(rb, ho + (hl + NM_OFS(qvel)), v_in, hl < kNV);
   stsv(rb, ho + (hl + NM_OFS(warm)), w_in, hl < kNV);
@@ -3242,11 +3246,12 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
 }
 
 // one wavefront = G consecutive envs (E2, env.py:200: mj_step(model, data, decimation) between load and epilogue)
-template <class real, int G> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave) {
+template <class real, int G, class Mid = NoMid> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave, Mid&& mid = Mid()) {
   nm_stamp(-1);
   if constexpr (G == 2) {
-    env_load2(w, M, A, wave);
+    env_load2(w, M, A, wave, mid);
   } else {
+    mid();
 #pragma unroll
     for (int e = 0; e < G; e++) {
       int env = wave * G + e;

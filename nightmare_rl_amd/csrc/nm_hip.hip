@@ -62,13 +62,20 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   if (wave * G >= A.N) return;
   const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   As = A;
-  {
+  __syncthreads();
+  // the model copy (L2 -> LDS) runs inside the load stage, after the env rows' HBM reads have been issued: one start-up round trip, not two
+  auto copy_model = [&]() {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(Mp);
     uint32_t* dst = reinterpret_cast<uint32_t*>(&Ms);
-    for (int i = threadIdx.x; i < (int)(sizeof(nm::Model<real>) / 4); i += 64) dst[i] = src[i];
+    constexpr int kWords = (int)(sizeof(nm::Model<real>) / 4);
+    uint32_t tmp[(kWords + 63) / 64];
+#pragma unroll
+    for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; tmp[k] = i < kWords ? src[i] : 0u; }
+#pragma unroll
+    for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; if (i < kWords) dst[i] = tmp[k]; }
     __syncthreads();
-  }
-  nm::wave_step<real, G>(sh, Ms, As, wave);
+  };
+  nm::wave_step<real, G>(sh, Ms, As, wave, copy_model);
   if (As.dbg && threadIdx.x == 0) {   // debug buffer only: start / end clock of this wave as exact 24-bit pieces (scripts/wavetimes.py)
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     real* d = As.dbg + (size_t)(wave * G) * nm::kDbgN + 250;
