@@ -2874,7 +2874,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 // length as int64, the command RNG) stays scalar, once per half. Every HBM read of BOTH envs is in flight before the first wait.
 // `mid()` runs after every HBM read has been issued and before the first of them is waited for: the kernel copies the model constants
 // (L2 -> LDS, `M` is that copy) there, so the two round trips of a wave's start-up overlap instead of following each other.
-struct NoMid { NM_FN void operator()() const {} };
+struct NoMid { NM_FN void operator()() const {} NM_FN void operator()(int) const {} };
 template <class real, class Mid> NM_FN void env_load2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave, Mid&& mid) {
   typedef V<real> vr;
   constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real)), kSI = (int)(sizeof(Sh<real>) / sizeof(int));
@@ -2957,7 +2957,11 @@ template <class real, class Mid> NM_FN void env_load2(ShW<real, 2>& w, const Mod
   wave_sync();
 }
 
-template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave, int dropped) {
+// `published()` runs as soon as everything this wave contributes to the end-of-step bookkeeping (the consumed atomics of E6 and of
+// the counters) is out: the kernel takes the wave's end-of-step ticket there, so the ticket's round trip is hidden under E7 / E8.
+// `published(1)` comes again after E7, a microsecond later: the group ticket is back by then, and the wave that turns out to be the last of
+// its group draws the top-level ticket there - under E8 and the buffer stores.
+template <class real, class Pub> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>& M, const Args<real>& A, int wave, int dropped, Pub&& published) {
   typedef V<real> vr;
   constexpr int kSR = (int)(sizeof(Sh<real>) / sizeof(real)), kSI = (int)(sizeof(Sh<real>) / sizeof(int));
   const V<int> lane = opaque_lane();
@@ -3117,6 +3121,7 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
 #endif
     epsum = sel(resetL, vr(real(0)), epsum);
   }
+  published(0);
   NM_ESTAMP(13);
   // ---- E7 (env.py:277-288, 399-497): rewards (alphabetical, termination last)
   vr rt[kNREW];
@@ -3181,6 +3186,7 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
     for (int k = 0; k < kNREW; k++) add = sel(hl == k, rt[k], add);
     gstv(A.epsum, hl + env * kNREW, epsum + add, live & (hl < kNREW));
   }
+  published(1);
   NM_ESTAMP(14);
   // ---- E8 (env.py:291-311): observation (66), clipped, float32
   if (!(NM_ABLATE(A.ablate) & 256)) {
@@ -3246,7 +3252,8 @@ template <class real> NM_FN void env_finish2(ShW<real, 2>& w, const Model<real>&
 }
 
 // one wavefront = G consecutive envs (E2, env.py:200: mj_step(model, data, decimation) between load and epilogue)
-template <class real, int G, class Mid = NoMid> NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave, Mid&& mid = Mid()) {
+template <class real, int G, class Mid = NoMid, class Pub = NoMid>
+NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A, int wave, Mid&& mid = Mid(), Pub&& published = Pub()) {
   nm_stamp(-1);
   if constexpr (G == 2) {
     env_load2(w, M, A, wave, mid);
@@ -3262,7 +3269,7 @@ template <class real, int G, class Mid = NoMid> NM_FN void wave_step(ShW<real, G
   int dropped = 0;
   for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, NM_ABLATE(A.ablate));
   if constexpr (G == 2) {
-    env_finish2(w, M, A, wave, dropped);
+    env_finish2(w, M, A, wave, dropped, published);
   } else {
 #pragma unroll
     for (int e = 0; e < G; e++) {

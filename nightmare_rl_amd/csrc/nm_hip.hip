@@ -75,7 +75,29 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
     for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; if (i < kWords) dst[i] = tmp[k]; }
     __syncthreads();
   };
-  nm::wave_step<real, G>(sh, Ms, As, wave, copy_model);
+  // Two-level ticket for "which wave closes the step": waves draw from their group's counter, the last wave of a group from the top
+  // counter - at most 64 + 32 same-address atomics in a row instead of gridDim.x. A wave draws its group ticket as soon as everything
+  // it contributes to the bookkeeping is published (inside the epilogue, before rewards and observation), so the round trip of that
+  // atomic is off the critical path of the wave that finishes last.
+  const int nw = (int)gridDim.x, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
+  const int gsize = min(nm::kTicketGroup, nw - grp * nm::kTicketGroup);
+  int ticket = 0, top = 0;
+  int stage = 0;                       // 0: nothing drawn, 1: group ticket drawn, 2: group ticket resolved (and the top one drawn if this wave closes its group)
+  bool closes_group = false;
+  auto draw = [&](int phase) {
+    if (phase == 0) {
+      if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done + (grp + 1) * nm::kTicketStride, 1);
+      stage = 1;
+    } else {
+      closes_group = __builtin_amdgcn_readfirstlane(ticket) == gsize - 1;
+      if (closes_group && threadIdx.x == 0) {
+        As.wave_done[(grp + 1) * nm::kTicketStride] = 0;     // every member has drawn: re-arm for the next launch
+        top = atomicAdd(As.wave_done + nm::kTicketTop, 1);
+      }
+      stage = 2;
+    }
+  };
+  nm::wave_step<real, G>(sh, Ms, As, wave, copy_model, draw);
   if (As.dbg && threadIdx.x == 0) {   // debug buffer only: start / end clock of this wave as exact 24-bit pieces (scripts/wavetimes.py)
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     real* d = As.dbg + (size_t)(wave * G) * nm::kDbgN + 250;
@@ -84,21 +106,11 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   }
   if (As.physics_only) return;
   // The wave that finishes last closes the step (what used to be a second launch). What it needs from the others went through
-  // device-scope atomics whose results each wave has already consumed (nm_consume), so the ticket needs no fence.
-  // Two-level ticket: waves draw from their group's counter, the last wave of a group from the top counter - at most 64 + 32
-  // same-address atomics in a row instead of gridDim.x.
-  const int nw = (int)gridDim.x, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
-  const int gsize = min(nm::kTicketGroup, nw - grp * nm::kTicketGroup);
-  int ticket = 0;
-  if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done + (grp + 1) * nm::kTicketStride, 1);
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != gsize - 1) return;
-  if (threadIdx.x == 0) {
-    As.wave_done[(grp + 1) * nm::kTicketStride] = 0;     // every member has drawn: re-arm for the next launch
-    ticket = atomicAdd(As.wave_done + nm::kTicketTop, 1);
-  }
-  ticket = __builtin_amdgcn_readfirstlane(ticket);
-  if (ticket != ngrp - 1) return;
+  // device-scope atomics whose results each wave has already consumed (nm_consume), so the tickets need no fence.
+  if (stage < 1) draw(0);              // paths that do not run the two-env epilogue draw here
+  if (stage < 2) draw(1);
+  if (!closes_group) return;
+  if (__builtin_amdgcn_readfirstlane(top) != ngrp - 1) return;
   step_tail<real>(As, Ms.ep_len_s);
 }
 
