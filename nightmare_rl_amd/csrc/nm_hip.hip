@@ -30,23 +30,44 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 // then the per-step accumulators are cleared for the next launch. One wave, after all others have published.
 template <class real> __device__ __noinline__ void step_tail(const nm::Args<real>& A, real ep_len_s) {
   const int lane = threadIdx.x;
-  const int cnt = __hip_atomic_load(A.stat_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // This runs behind the launch's last wave, alone: every global access is a full round trip that nothing hides. So the reads are
+  // issued in two batches - everything that is addressed by the lane alone, then the two lists those counts index - not one by one.
+#define TAIL_LD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+  const int cnt = TAIL_LD(A.stat_cnt);
+  const int c1 = TAIL_LD(A.stat_cnt + 1), c2 = TAIL_LD(A.stat_cnt + 2);
+  const real ssum = TAIL_LD(A.stat_sum + (lane < nm::kNREW ? lane : 0));
+  const int n = TAIL_LD(A.nto);
+  const int np = TAIL_LD(A.nprev);
+  const long long k0 = lane == 0 ? A.counters[0] : 0, k1 = lane == 0 ? A.counters[1] : 0;
   if (cnt > 0) {
-    if (lane < nm::kNREW && A.ep_stats) {
-      const real s = __hip_atomic_load(A.stat_sum + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      A.ep_stats[lane] = (float)(s / (real)cnt / ep_len_s);
-    }
-    if (A.time_outs) {   // all zeros, then ones at the envs on the time-out list (time-outs are a subset of the resets)
-      for (int i = lane; i < A.N; i += 64) A.time_outs[i] = 0.f;
-      const int n = __hip_atomic_load(A.nto, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < nm::kNREW && A.ep_stats) A.ep_stats[lane] = (float)(ssum / (real)cnt / ep_len_s);
+    if (A.time_outs) {
+      // extras['time_outs'] = this step's time-out flags (a subset of the resets). The buffer still holds what the last refresh
+      // wrote, so only the entries that were 1 are cleared and the new ones set: O(time-outs) instead of N stores.
+      // A buffer this env has not written before (to_full) is rewritten completely.
+      const int e_new = lane < n ? TAIL_LD(A.to_list + lane) : -1;
+      const int e_old = (!A.to_full && lane < np) ? A.to_prev[lane] : -1;
+      if (A.to_full) {
+        for (int i = lane; i < A.N; i += 64) A.time_outs[i] = 0.f;
+      } else {
+        if (e_old >= 0) A.time_outs[e_old] = 0.f;
+        for (int j = lane + 64; j < np; j += 64) A.time_outs[A.to_prev[j]] = 0.f;
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the zeros have reached L2 before a one goes to the same address
-      for (int j = lane; j < n; j += 64) A.time_outs[__hip_atomic_load(A.to_list + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)] = 1.f;
+      if (e_new >= 0) { A.time_outs[e_new] = 1.f; A.to_prev[lane] = e_new; }
+      for (int j = lane + 64; j < n; j += 64) {
+        const int e = TAIL_LD(A.to_list + j);
+        A.time_outs[e] = 1.f;
+        A.to_prev[j] = e;
+      }
+      if (lane == 0) *A.nprev = n;
     }
   }
+#undef TAIL_LD
   if (lane < nm::kNREW) A.stat_sum[lane] = real(0);
   if (lane == 0) {
-    A.counters[0] += __hip_atomic_load(A.stat_cnt + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    A.counters[1] += __hip_atomic_load(A.stat_cnt + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    A.counters[0] = k0 + c1;
+    A.counters[1] = k1 + c2;
     A.stat_cnt[0] = 0; A.stat_cnt[1] = 0; A.stat_cnt[2] = 0; A.stat_cnt[3] = 0;
     *A.nto = 0;
     A.wave_done[nm::kTicketTop] = 0;
@@ -111,7 +132,9 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   if (stage < 2) draw(1);
   if (!closes_group) return;
   if (__builtin_amdgcn_readfirstlane(top) != ngrp - 1) return;
+#ifndef NM_SKIP_TAIL2
   step_tail<real>(As, Ms.ep_len_s);
+#endif
 }
 
 // reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
@@ -200,6 +223,7 @@ template <class real> struct Env : nm_env {
   real* cmd_u_dev = nullptr;
   bool cmd_u_on = false;
   float* timeout_now = nullptr;
+  float* last_time_outs = nullptr;   // the caller's extras['time_outs'] buffer of the previous step() (device pointer, compared only)
   int32_t* ids_dev = nullptr;
   long long* counters_dev = nullptr;
   nm::Model<real>* M_dev = nullptr;
@@ -262,7 +286,7 @@ template <class real> struct Env : nm_env {
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
         dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * nm::kNREW) || dalloc(&A.feetair, n_ * nm::kNLEG) || dalloc(&A.feetflags, n_) ||
         dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, nm::kNREW) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
-        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, ((n_ + nm::kTicketGroup - 1) / nm::kTicketGroup + 2) * nm::kTicketStride) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_))
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, ((n_ + nm::kTicketGroup - 1) / nm::kTicketGroup + 2) * nm::kTicketStride) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_) || dalloc(&A.nprev, 1) || dalloc(&A.to_prev, n_))
       return 1;
     if (dalloc(&M_dev, 1)) return 1;
     HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));
@@ -313,6 +337,8 @@ template <class real> struct Env : nm_env {
     a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
     a.physics_only = physics_only;
     a.ep_stats = ep_stats; a.time_outs = time_outs; a.counters = counters_dev;
+    a.to_full = (time_outs != last_time_outs) ? 1 : 0;   // see step_tail: incremental refresh needs the buffer it wrote last time
+    if (!physics_only) last_time_outs = time_outs;
     if (!physics_only) {
       a.noise_vec = noise_on ? noise_vec_dev : nullptr;
       a.noise_u = noise_on && noise_u_on ? noise_u_dev : nullptr;
