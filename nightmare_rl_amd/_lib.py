@@ -34,6 +34,16 @@ _measure = None
 MEASURE_LIB_PATH = os.path.join(HERE, "csrc", "libnightmare_hip_measure.so")
 
 
+def _import_torch_first():
+    """PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so). If this library is dlopen'ed before torch has been imported,
+    the system runtime it links against comes first and the process ends up with two HIP runtimes - the later one sees no device
+    ("nm_create: no HIP device available" although torch.cuda.is_available()). Importing torch first makes its runtime the process's."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def load():
     """Load the HIP extension. Raises if it has not been built (python __graft_entry__.py / make -C nightmare_rl_amd/csrc)."""
     global _lib
@@ -42,6 +52,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise NightmareHipError(f"{LIB_PATH} not found: build the HIP extension first (python -c 'import __graft_entry__ as g; g.build()'). "
                                 "There is no CPU fallback.")
+    _import_torch_first()
     _lib = _bind(C.CDLL(LIB_PATH), full=True)
     return _lib
 
@@ -53,6 +64,7 @@ def load_measure():
     if _measure is None:
         if not os.path.exists(MEASURE_LIB_PATH):
             raise NightmareHipError(f"{MEASURE_LIB_PATH} not found: make -C nightmare_rl_amd/csrc measure")
+        _import_torch_first()
         _measure = _bind(C.CDLL(MEASURE_LIB_PATH), full=False)
         _measure.nm_set_ablation.argtypes = [C.c_void_p, C.c_int32]
     return _measure
