@@ -193,27 +193,31 @@ def main():
             env.step_physics(acts[i % pool])
         torch.cuda.synchronize(dev)
         phys = E * 200 / (time.perf_counter() - t1)
-        # config 3: policy forward (66->256->256->18, exact-f32 MFMA) + step(), closed loop, replayed as ONE HIP graph per
-        # step (policy kernel + step kernel + extras kernel) so the host launch path is off the critical path
+        # config 3: policy forward (66->256->256->18, exact-f32 MFMA) + step(), closed loop: observation -> actions -> step -> observation.
+        # One HIP graph holds 40 such steps (the PPO runner captures its 80-step rollout the same way), so neither the host launch
+        # path nor a per-step graph launch sits between the kernels. An even number of steps: the env alternates two observation
+        # buffers, and a graph replays fixed addresses.
         net = ActorMLP([66, 256, 256, 18]).to(dev)
-        obs = env.get_observations()
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
-            for i in range(5):
-                env.step(net(obs))
+            for i in range(6):
+                env.step(net(env.get_observations()))
         torch.cuda.current_stream(dev).wait_stream(side)
+        per_graph = 40
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            env.step(net(obs))
-        for i in range(20):
+            o = env.get_observations()
+            for i in range(per_graph):
+                o = env.step(net(o))[0]
+        for i in range(3):
             graph.replay()
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
-        for i in range(300):
+        for i in range(10):
             graph.replay()
         torch.cuda.synchronize(dev)
-        closed = E * 300 / (time.perf_counter() - t1)
+        closed = E * 10 * per_graph / (time.perf_counter() - t1)
         # the fp64 verification build of the same kernel (what the exact-parity tests run)
         cfg64 = NightmareV3Config()
         cfg64.env.num_envs = E
