@@ -158,6 +158,7 @@ template <class real> struct Sh {
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
   int nhop;
+  int ntog;                       // [env 0 of a wave] substeps of this step whose constraint stage took both envs in one pass (debug buffer only)
   real eact[kNU], epact[kNU], epdv[kNU];  // this step's clipped actions, last step's actions and joint velocities (epilogue inputs)
   real ecmd[4], eepsum[kNREW];    // env buffers fetched at load time for the epilogue: commands, episode sums
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
@@ -2507,6 +2508,7 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
 #ifdef NM_EMUL
       nm_emul_together() += 1;
 #endif
+      w.e[0].ntog += 1;
       stage_constraint2(w, M, last, (ablate & 2) != 0);
       nm_stamp(8);
     }
@@ -2553,6 +2555,7 @@ template <class real> NM_FN void env_load(Sh<real>& sh, const Model<real>& M, co
   stsv(sh.hcache, lane, sel(lane == 0, hc_in & V<int>(0xffff), hc_in), lane < 8);     // bits 16.. of [0]: load hint of the two-env build
   sh.nwarn = 0;
   sh.nhop = 0;
+  sh.ntog = 0;
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
   V<float> af = a_in * M.action_scale;
   af = vmin(vmax(af, V<float>(-M.clip_actions)), V<float>(M.clip_actions));
@@ -2603,6 +2606,7 @@ template <class real> NM_FN void env_debug(Sh<real>& sh, const Args<real>& A, in
     gstv(dbg, V<int>(158), to_real<real>(sh.hcache[7]), lane == 0);
     gstv(dbg, V<int>(159), to_real<real>(sh.nhop), lane == 0);
     gstv(dbg, V<int>(157), to_real<real>(sh.anypair), lane == 0);
+    gstv(dbg, V<int>(156), to_real<real>(sh.ntog), lane == 0);
     gstv(dbg, V<int>(163), to_real<real>(sh.it_pgs), lane == 0);
     gstv(dbg, V<int>(164), to_real<real>(sh.it_noslip), lane == 0);
     gstv(dbg, lane + 176, ldsv(sh.efc_f, lane), lane < kMaxRow);
@@ -2920,6 +2924,7 @@ template <class real, class Mid> NM_FN void env_load2(ShW<real, 2>& w, const Mod
   nm_set_priority((rdlane(hc_in, 0) >> 16) + (rdlane(hc_in, 32) >> 16));
   w.e[0].nwarn = 0; w.e[1].nwarn = 0;
   w.e[0].nhop = 0; w.e[1].nhop = 0;
+  w.e[0].ntog = 0; w.e[1].ntog = 0;
   // ---- E1 (env.py:152-156,181-192): float32 scale + clip; PD -> velocity command from the env's own dof_pos buffer
   V<float> af = a_in * M.action_scale;
   af = vmin(vmax(af, V<float>(-M.clip_actions)), V<float>(M.clip_actions));
