@@ -73,7 +73,9 @@ int nm_reset(nm_env* env, const int32_t* ids_host, int32_t n, int64_t* episode_l
  *   episode_length_dev [N] i64   in/out (episode_length_buf)
  *   obs_dev [N,66] f32, rew_dev [N] f32, done_dev [N] i64: the returned tuple (:311)
  *   time_outs_dev [N] f32, ep_stats_dev [NM_NUM_REWARDS] f32: extras; like the reference (:344-371) they are only
- *   refreshed by a step in which at least one env reset. */
+ *   refreshed by a step in which at least one env reset. A refresh of the buffer the previous refresh wrote is incremental (its
+ *   ones are cleared, the new ones set), so the caller must not write into time_outs_dev between steps; any other buffer
+ *   (a first call, a new allocation) is rewritten in full - decided on the device, also for launches replayed from a graph. */
 int nm_step(nm_env* env, const float* actions_dev, int64_t* episode_length_dev, float* obs_dev, float* rew_dev,
             int64_t* done_dev, float* time_outs_dev, float* ep_stats_dev, void* stream);
 

@@ -110,7 +110,7 @@ template <class real> struct Args {
                          // [kTicketTop] over the groups (one counter for 2048 waves serialises ~25 us of same-address atomics)
   int *nto, *to_list;    // [1], [N]: envs that timed out in this launch (what the closing wave turns into extras['time_outs'])
   int *nprev, *to_prev;  // [1], [N]: the envs whose time_outs entry the last refresh set to 1 (cleared one by one at the next refresh)
-  int to_full;           // 1: the caller's time_outs buffer is not the one the last refresh wrote - rewrite all N entries
+  unsigned long long* to_owner;   // [1] address of the time_outs buffer the last refresh wrote (another buffer is rewritten in full)
   float *ep_stats, *time_outs;   // [kNREW] extras['episode'], [N] extras['time_outs']
   long long* counters;   // [3] running totals of stat_cnt[1..3]
   real* dbg;             // optional [N][kDbgN]

@@ -38,16 +38,18 @@ template <class real> __device__ __noinline__ void step_tail(const nm::Args<real
   const real ssum = TAIL_LD(A.stat_sum + (lane < nm::kNREW ? lane : 0));
   const int n = TAIL_LD(A.nto);
   const int np = TAIL_LD(A.nprev);
+  // decided on the device, so that it also holds for a launch replayed from a graph: is this the buffer the last refresh wrote?
+  const bool to_full = A.time_outs && TAIL_LD(A.to_owner) != (unsigned long long)(uintptr_t)A.time_outs;
   const long long k0 = lane == 0 ? A.counters[0] : 0, k1 = lane == 0 ? A.counters[1] : 0;
   if (cnt > 0) {
     if (lane < nm::kNREW && A.ep_stats) A.ep_stats[lane] = (float)(ssum / (real)cnt / ep_len_s);
     if (A.time_outs) {
       // extras['time_outs'] = this step's time-out flags (a subset of the resets). The buffer still holds what the last refresh
       // wrote, so only the entries that were 1 are cleared and the new ones set: O(time-outs) instead of N stores.
-      // A buffer this env has not written before (to_full) is rewritten completely.
+      // A buffer other than the one the last refresh wrote (to_full) is rewritten completely.
       const int e_new = lane < n ? TAIL_LD(A.to_list + lane) : -1;
-      const int e_old = (!A.to_full && lane < np) ? A.to_prev[lane] : -1;
-      if (A.to_full) {
+      const int e_old = (!to_full && lane < np) ? A.to_prev[lane] : -1;
+      if (to_full) {
         for (int i = lane; i < A.N; i += 64) A.time_outs[i] = 0.f;
       } else {
         if (e_old >= 0) A.time_outs[e_old] = 0.f;
@@ -60,7 +62,7 @@ template <class real> __device__ __noinline__ void step_tail(const nm::Args<real
         A.time_outs[e] = 1.f;
         A.to_prev[j] = e;
       }
-      if (lane == 0) *A.nprev = n;
+      if (lane == 0) { *A.nprev = n; *A.to_owner = (unsigned long long)(uintptr_t)A.time_outs; }
     }
   }
 #undef TAIL_LD
@@ -223,7 +225,6 @@ template <class real> struct Env : nm_env {
   real* cmd_u_dev = nullptr;
   bool cmd_u_on = false;
   float* timeout_now = nullptr;
-  float* last_time_outs = nullptr;   // the caller's extras['time_outs'] buffer of the previous step() (device pointer, compared only)
   int32_t* ids_dev = nullptr;
   long long* counters_dev = nullptr;
   nm::Model<real>* M_dev = nullptr;
@@ -286,7 +287,7 @@ template <class real> struct Env : nm_env {
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
         dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * nm::kNREW) || dalloc(&A.feetair, n_ * nm::kNLEG) || dalloc(&A.feetflags, n_) ||
         dalloc(&A.rngctr, n_) || dalloc(&A.hullcache, n_ * 8) || dalloc(&A.stat_sum, nm::kNREW) || dalloc(&A.stat_cnt, 4) || dalloc(&cmd_u_dev, n_ * 4) ||
-        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, ((n_ + nm::kTicketGroup - 1) / nm::kTicketGroup + 2) * nm::kTicketStride) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_) || dalloc(&A.nprev, 1) || dalloc(&A.to_prev, n_))
+        dalloc(&timeout_now, n_) || dalloc(&ids_dev, n_) || dalloc(&counters_dev, 4) || dalloc(&A.wave_done, ((n_ + nm::kTicketGroup - 1) / nm::kTicketGroup + 2) * nm::kTicketStride) || dalloc(&A.nto, 1) || dalloc(&A.to_list, n_) || dalloc(&A.nprev, 1) || dalloc(&A.to_prev, n_) || dalloc(&A.to_owner, 1))
       return 1;
     if (dalloc(&M_dev, 1)) return 1;
     HIPCHK(hipMemcpy(M_dev, &M, sizeof M, hipMemcpyHostToDevice));
@@ -337,8 +338,6 @@ template <class real> struct Env : nm_env {
     a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
     a.physics_only = physics_only;
     a.ep_stats = ep_stats; a.time_outs = time_outs; a.counters = counters_dev;
-    a.to_full = (time_outs != last_time_outs) ? 1 : 0;   // see step_tail: incremental refresh needs the buffer it wrote last time
-    if (!physics_only) last_time_outs = time_outs;
     if (!physics_only) {
       a.noise_vec = noise_on ? noise_vec_dev : nullptr;
       a.noise_u = noise_on && noise_u_on ? noise_u_dev : nullptr;

@@ -144,3 +144,40 @@ def test_observation_survives_the_next_step_like_rsl_rl_needs():
         assert obs.data_ptr() != kept.data_ptr()
         assert env.get_observations() is obs
         assert not torch.equal(obs, witness)               # and the new observation really is new
+
+
+def test_time_outs_refresh_is_incremental_on_its_own_buffer_and_full_on_any_other():
+    """extras['time_outs'] (env.py:369-371) is refreshed by the launch's closing wave: on the buffer its last refresh wrote it only
+    clears that refresh's ones and sets the new ones; a buffer it has not written (first call, a new tensor - here one filled with
+    garbage) must come out completely rewritten. Steps without a reset leave the vector alone, like the reference (env.py:344)."""
+    N = 256
+    env = make_env(N, seed=4)
+    env.reset()
+    zero = torch.zeros(N, 18)
+
+    def step_with_timeouts(ids):
+        env.episode_length_buf = torch.zeros(N, dtype=torch.int64, device="cuda")
+        env.episode_length_buf[ids] = 1250                      # -> 1251 > max_episode_length: these time out in this step
+        _, _, _, done, extras = env.step(zero)
+        return done.cpu().numpy(), extras["time_outs"].cpu().numpy()
+
+    ids1 = torch.tensor([3, 64, 200])
+    done, to = step_with_timeouts(ids1)
+    want = np.zeros(N, np.float32); want[ids1.numpy()] = 1
+    np.testing.assert_array_equal(to, want)
+    assert done[ids1.numpy()].all()
+    ids2 = torch.tensor([5, 64, 255, 17])                       # incremental: 3 and 200 cleared, 64 stays set, three new ones
+    done, to = step_with_timeouts(ids2)
+    want = np.zeros(N, np.float32); want[ids2.numpy()] = 1
+    np.testing.assert_array_equal(to, want)
+    env.time_out_buf = torch.full((N,), 7.0, device="cuda")     # another buffer: must be rewritten in full
+    env.extras.pop("time_outs", None); env._fill_extras()
+    ids3 = torch.tensor([9])
+    done, to = step_with_timeouts(ids3)
+    want = np.zeros(N, np.float32); want[9] = 1
+    np.testing.assert_array_equal(to, want)
+    # a step in which no env resets leaves the vector as it is (robots standing still on the ground: no fall within one step)
+    env.episode_length_buf = torch.full((N,), 10, dtype=torch.int64, device="cuda")
+    _, _, _, done, extras = env.step(zero)
+    if int(done.sum()) == 0:
+        np.testing.assert_array_equal(extras["time_outs"].cpu().numpy(), want)
