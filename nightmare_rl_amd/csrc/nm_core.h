@@ -1015,8 +1015,11 @@ template <class real> NM_FN int support_exhaustive(const Model<real>& M, const r
     best = sel(take, val, best);
     ibest = sel(take, vi, ibest);
   }
+  // one lane holds the maximum in all but exact ties: then its vertex is the answer without carrying indices through the reduction
   real sv; int si;
-  wargmax(best, ibest, &sv, &si);
+  wmaxfirst(best, &sv, &si);
+  if (popc64(ballot(best == vr(sv))) == 1) return rdlane(ibest, si);
+  wargmax(best, ibest, &sv, &si);   // exact tie across lanes: the lowest vertex index wins (the reference rule)
   return si;
 }
 template <class real> NM_FN real hull_tie_tol() { return sizeof(real) == 8 ? real(1e-13) : real(4e-7); }  // metres; >> rounding of ld.v
@@ -1085,8 +1088,11 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
         const VB nbv = nbl & (nb[g] >= 0);
         if (!wany(nbv & (val[g] >= vr(sv[g] - tol)))) break;
         if (hop == kMaxHop || !wany(nbv & (val[g] > vr(sv[g] + tol)))) { full = true; break; }
-        real bv;
-        wargmax(sel(nbv, val[g], vr(real(-1e30))), nb[g], &bv, &si);
+        // the best neighbour; among exactly equal ones any will do (the climb only has to arrive: a strict maximum is THE support
+        // vertex of a convex hull, anything else goes to the exhaustive scan and its lowest-index rule)
+        real bv; int lbest;
+        wmaxfirst(sel(nbv, val[g], vr(real(-1e30))), &bv, &lbest);
+        si = rdlane(nb[g], lbest);
         NM_BSTAMP(12);
         hull_ring(M, vadr + si, si, nb[g], vv[g]);
         val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];

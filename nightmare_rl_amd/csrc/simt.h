@@ -165,6 +165,18 @@ template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
   *best = bv;
   *ibest = bi;
 }
+// wave maximum and the FIRST lane that holds it (no index carried through the reduction: 4 DPP max + 3 readlane merges + a ballot;
+// wargmax costs three times that). For callers to whom any lane of the maximum is as good as another.
+template <class T> NM_FN void wmaxfirst(T val, T* best, int* lane_of_best) {
+  T m = val;
+  m = vmax(m, dpp<NM_DPP_QUAD_XOR1>(m));
+  m = vmax(m, dpp<NM_DPP_QUAD_XOR2>(m));
+  m = vmax(m, dpp<NM_DPP_HALF_MIRROR>(m));
+  m = vmax(m, dpp<NM_DPP_ROW_MIRROR>(m));
+  const T b = vmax(vmax(rdlane(m, 0), rdlane(m, 16)), vmax(rdlane(m, 32), rdlane(m, 48)));
+  *best = b;
+  *lane_of_best = (int)__builtin_ctzll(__ballot(val == b));
+}
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
 template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; }
 // masked LDS store without a branch: lanes outside the mask write their value to their own word of a scratch row instead. A masked
@@ -300,6 +312,11 @@ template <class T> NM_FN void wargmax(V<T> val, V<int> idx, T* best, int* ibest)
   for (int i = 1; i < NM_WAVE; i++)
     if (val.v[i] > bv || (val.v[i] == bv && idx.v[i] < bi)) { bv = val.v[i]; bi = idx.v[i]; }
   *best = bv; *ibest = bi;
+}
+template <class T> NM_FN void wmaxfirst(const V<T>& val, T* best, int* lane_of_best) {
+  T bv = val.v[0]; int bi = 0;
+  for (int i = 1; i < NM_WAVE; i++) if (val.v[i] > bv) { bv = val.v[i]; bi = i; }
+  *best = bv; *lane_of_best = bi;
 }
 template <class T> NM_FN V<T> ldsv(const T* a, const V<int>& i) { V<T> r; for (int k = 0; k < NM_WAVE; k++) r.v[k] = a[i.v[k]]; return r; }
 template <class T> NM_FN T ldsv(const T* a, int i) { return a[i]; }
