@@ -1133,7 +1133,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       const real tol = M.tol_planemesh * M.colc[kColN * g + 3];
       vr dd[3] = {pnt[0] - first[0], pnt[1] - first[1], pnt[2] - first[2]};
       vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
-      const VB ok = nbl & (nb[g] >= 0) & (val[g] > vr(pz[g])) & !(vsqrt(d2) < vr(tol));
+      const VB ok = nbl & (nb[g] >= 0) & (val[g] > vr(pz[g])) & !(d2 < vr(tol * tol));     // |.| < tol without the square root
       const uint64_t m = ballot(ok);
       nextra = vmin(popc64(m), 3);
       const V<int> rank = lane_rank(m);
@@ -1147,10 +1147,8 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       stsu(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr, sh.sink);
       stsu(sh.cdist(), sl, cd, wr, sh.sink);
       stsu(sh.cleg(), sl, V<int>(g - 1), wr, sh.sink);
-      stsu(sh.cleg1(), sl, V<int>(-1), wr, sh.sink);
-      stsu(sh.cnrm(), sl * 3, vr(real(0)), wr, sh.sink);
-      stsu(sh.cnrm(), sl * 3 + 1, vr(real(0)), wr, sh.sink);
-      stsu(sh.cnrm(), sl * 3 + 2, vr(real(1)), wr, sh.sink);
+      // (a floor contact's normal (0,0,1) and "no first body" are not stored here: only the rare constraint paths read them, and
+      // those fill them in first - floor_frames())
     }
     const int ng = hitg ? 1 + nextra : 0;
     const int c0 = vmin(total, kMaxConBig), c1 = vmin(total + ng, kMaxConBig);
@@ -1161,6 +1159,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
   const int ncon = vmin(total, kMaxConBig);
   *dropped += total - ncon;
   sh.ncon = ncon;
+  sh.cstart[7] = ncon;       // number of floor contacts (the tibia-pair contacts follow them)
   sh.anypair = 0;
   wave_sync();
   NM_BSTAMP(13);
@@ -2291,9 +2290,22 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
   }
   wave_sync();
 }
+// contact frame and first body of the floor contacts: constants that stage B does not store; the two rare paths that read the
+// general contact record (tibia pairs present, more than kMaxCon contacts) get them here
+template <class real> NM_COLD void floor_frames(Sh<real>& sh) {
+  const V<int> lane = lane_id();
+  const int nfloor = uniform(sh.cstart[7]);
+  const VB on = lane < nfloor;                  // nfloor <= 28 < 64
+  const V<int> c = sel(on, lane, V<int>(0));
+  stsv(sh.cleg1(), c, V<int>(-1), on);
+  stsv(sh.cnrm(), c * 3, V<real>(real(0)), on);
+  stsv(sh.cnrm(), c * 3 + 1, V<real>(real(0)), on);
+  stsv(sh.cnrm(), c * 3 + 2, V<real>(real(1)), on);
+  wave_sync();
+}
 template <class real> NM_FN void stage_constraint(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep = false) {
-  if (uniform(sh.ncon) > kMaxCon) stage_constraint_big<real>(sh, M, last, nosweep);
-  else if (uniform(sh.anypair) != 0) stage_constraint_pairs<real>(sh, jrow, M, last, nosweep);
+  if (uniform(sh.ncon) > kMaxCon) { floor_frames(sh); stage_constraint_big<real>(sh, M, last, nosweep); }
+  else if (uniform(sh.anypair) != 0) { floor_frames(sh); stage_constraint_pairs<real>(sh, jrow, M, last, nosweep); }
   else stage_constraint_body<real, false>(sh, jrow, M, last, nosweep);
 }
 

@@ -81,7 +81,16 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   __shared__ nm::ShW<real, G> sh;
   __shared__ nm::Model<real> Ms;   // this wave's copy of the model constants
   __shared__ nm::Args<real> As;    // ... and of the launch arguments: ~30 pointers would otherwise pin 60 SGPRs for the whole kernel
-  const int wave = blockIdx.x;
+  // XCD-aware block -> wave mapping: the dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8), each with
+  // its own L2. Consecutive envs share cache lines (rows of 100 / 96 / 72 bytes), so each XCD takes a CONTIGUOUS eighth of the waves:
+  // a line's bytes are then written through one L2 instead of being merged in memory from two.
+  int wave = blockIdx.x;
+#ifndef NM_NO_XCD_MAP
+  {
+    const int nwx = (int)gridDim.x >> 3;          // waves per XCD (the remainder, if any, keeps the identity mapping)
+    if (wave < (nwx << 3)) wave = (wave & 7) * nwx + (wave >> 3);
+  }
+#endif
   if (wave * G >= A.N) return;
   const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   As = A;
