@@ -401,6 +401,11 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
   vr Rb[9];
   {
     vr qw = LDG(qpos, 3), qx = LDG(qpos, 4), qy = LDG(qpos, 5), qz = LDG(qpos, 6);
+    {  // mj_kinematics normalises the free joint's quaternion in qpos (every lane of the env's groups does, and stores, the same)
+      const vr in_ = vrcp(vsqrt(qw * qw + qx * qx + qy * qy + qz * qz));
+      qw = qw * in_; qx = qx * in_; qy = qy * in_; qz = qz * in_;
+      STG(qpos, 3, qw); STG(qpos, 4, qx); STG(qpos, 5, qy); STG(qpos, 6, qz);
+    }
     vr q00 = qw * qw, q01 = qw * qx, q02 = qw * qy, q03 = qw * qz, q11 = qx * qx, q12 = qx * qy, q13 = qx * qz, q22 = qy * qy,
        q23 = qy * qz, q33 = qz * qz;
     Rb[0] = q00 + q11 - q22 - q33; Rb[4] = q00 - q11 + q22 - q33; Rb[8] = q00 - q11 - q22 + q33;
@@ -2481,14 +2486,7 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
           if ((bm >> (32 * e)) & 0xffffffffull) { w.e[e].nwarn += 1; reset_data(w.e[e], M); }
       }
     }
-    {  // mj_kinematics normalises the free joint's quaternion in qpos: lanes 3..6 of each half hold the four components
-      const V<real> q3 = ldsv(rbw, ho + (3 + NM_OFS(qpos))), q4 = ldsv(rbw, ho + (4 + NM_OFS(qpos))), q5 = ldsv(rbw, ho + (5 + NM_OFS(qpos))),
-                    q6 = ldsv(rbw, ho + (6 + NM_OFS(qpos)));
-      const V<real> n = vsqrt(q3 * q3 + q4 * q4 + q5 * q5 + q6 * q6);
-      const V<real> mine = sel(hl == 3, q3, sel(hl == 4, q4, sel(hl == 5, q5, q6)));
-      wave_sync();
-      stsv(rbw, ho + (hl + NM_OFS(qpos)), mine * vrcp(n), (hl >= 3) & (hl <= 6));
-    }
+    // (mj_kinematics' normalisation of the free joint's quaternion happens at the head of stage A, in registers)
   } else {
     for (int e = 0; e < G; e++) {
       Sh<real>& sh = w.e[e];
@@ -2496,13 +2494,6 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
         VB bad = (visbad(ldsv(sh.qpos, sel(lane < kNQ, lane, V<int>(0)))) & (lane < kNQ)) |
                  (visbad(ldsv(sh.qvel, sel(lane < kNV, lane, V<int>(0)))) & (lane < kNV));
         if (wany(bad)) { sh.nwarn += 1; reset_data(sh, M); }
-      }
-      {  // mj_kinematics normalises the free joint's quaternion in qpos
-        real n = vsqrt(sh.qpos[3] * sh.qpos[3] + sh.qpos[4] * sh.qpos[4] + sh.qpos[5] * sh.qpos[5] + sh.qpos[6] * sh.qpos[6]);
-        const real in_ = vrcp(n);
-        real a = sh.qpos[3] * in_, b = sh.qpos[4] * in_, c = sh.qpos[5] * in_, d = sh.qpos[6] * in_;
-        wave_sync();
-        sh.qpos[3] = a; sh.qpos[4] = b; sh.qpos[5] = c; sh.qpos[6] = d;
       }
     }
   }
