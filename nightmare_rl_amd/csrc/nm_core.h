@@ -2323,7 +2323,7 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
   real* lds = reinterpret_cast<real*>(&w.e[0]);
   const Grp<real, G> gp;
   const V<int> leg = gp.leg, eo = gp.eo;
-  const VB isleg = gp.isleg, lead = gp.lead;
+  const VB isleg = gp.sub < V<int>(6);   // as in stage A: every lane group computes (and stores) its env's values, duplicates included
 #define LDG(field, i) ldsv(lds, eo + (NM_OFS(field) + (i)))
 #define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
   vr qacc_l[3], qint_l[3], qacc_b[6], qint_b[6];
@@ -2371,8 +2371,9 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
   VB badl = (visbad(qacc_l[0]) | visbad(qacc_l[1]) | visbad(qacc_l[2])) & isleg;
 #pragma unroll
   for (int j = 0; j < 6; j++) badl = badl | visbad(qacc_b[j]);
-  const VB gbad = gsum8(sel(badl & gp.gact, V<int>(1), V<int>(0))) > 0;
-  const VB okl = isleg & !gbad, okb = lead & !gbad;
+  const VB gbad = gsum8(sel(badl, V<int>(1), V<int>(0))) > 0;
+  // unmasked stores (stage A's argument); an env with a bad qacc stores garbage here and is rewritten completely by the cold path below
+  const VB okl = VB(true), okb = VB(true);
   wave_sync();
   // mj_advance: qacc_warmstart <- qacc ; qvel += h qacc_int ; qpos integrates the NEW velocity
   vr nv[6];
