@@ -43,11 +43,15 @@ struct MlpArgs {
   const float* b[kMaxLayers];
   int dims[kMaxLayers + 1];
   int n_layers, N;
+  const f32x4* wt_last;         // the last layer once more, packed in the k order of the previous layer's accumulators (fuse_last)
+  int fuse_last;                // 1: the last layer is computed from the previous layer's registers (see k_mlp_fused)
 };
 
 // W [O,K] row-major (torch.nn.Linear) -> packed B operand: lane (r = l & 15, q = l >> 4) of tile t needs, at k-step s,
 // W[16 t + r][4 s + q]; zero beyond K or O.
-__global__ void k_pack_weights(const float* __restrict__ W, f32x4* __restrict__ P, int O, int K, int ngrp, int ntile) {
+// korder 1: lane (r, q) of group gs holds k = 16 gs + 4 q + j (j = 0..3) - the order in which a lane of the PREVIOUS layer's transposed
+// product holds its features (16 t + 4 q + reg), so those accumulators can be this layer's B operand without leaving the registers.
+__global__ void k_pack_weights(const float* __restrict__ W, f32x4* __restrict__ P, int O, int K, int ngrp, int ntile, int korder) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= ntile * ngrp * 64) return;
   const int lane = i & 63, gs = (i >> 6) % ngrp, t = (i >> 6) / ngrp;
@@ -55,7 +59,7 @@ __global__ void k_pack_weights(const float* __restrict__ W, f32x4* __restrict__ 
   f32x4 v;
 #pragma unroll
   for (int j = 0; j < 4; j++) {
-    const int k = 4 * (4 * gs + j) + q;
+    const int k = korder ? 16 * gs + 4 * q + j : 4 * (4 * gs + j) + q;
     v[j] = (col < O && k < K) ? W[(size_t)col * K + k] : 0.0f;
   }
   P[i] = v;
@@ -189,22 +193,40 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restri
     float* y = act[(l + 1) & 1];
     f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
     // biases of this wave's two column tiles: requested now, needed in the epilogue
-    const int bc0 = 16 * p.t0 + r, bc1 = 16 * p.t1 + r;
     // unconditional (index clamped; columns >= O are masked where they are stored): a conditional load compiles to `v = 0; if (..) v = load`,
     // and the write of the 0 into a register that a load of the previous layer targeted costs an s_waitcnt vmcnt(0) at the loop head -
     // i.e. a wait for the whole weight ring that was prefetched across the barrier
-    const float bias0 = B[min(bc0, O - 1)], bias1 = B[min(bc1, O - 1)];
+    // In the transposed product a lane's four accumulator registers are four FEATURES (16 t + 4 q + reg) of ONE batch row (lane & 15).
+    float bias0[4], bias1[4];
+#pragma unroll
+    for (int reg = 0; reg < 4; reg++) {
+      bias0[reg] = B[min(16 * p.t0 + 4 * q + reg, O - 1)];
+      bias1[reg] = B[min(16 * p.t1 + 4 * q + reg, O - 1)];
+    }
     // The layer as kRing-aligned steps: n real ones (8 MFMAs each), padded with MFMA-free steps to nv = 8 or 16. Every step refills the
     // ring slot it has just consumed: with group i + kRing of this layer while there is one, then with the NEXT layer's groups - the
     // padding makes next-layer group j land in slot j % kRing, where that layer's step j will look for it. So the first kRing groups
     // of a layer are requested during the previous layer's last kRing steps, not after its MFMAs (where the first step then sat out
     // an L2 round trip under load: ~2 us per layer boundary in the stamps), and the fill in front of layer 0 is the only other one.
+    // Fused last layer: this is the layer before it and the handle found the shapes fit (nm_policy_create). Its weights for this wave's
+    // two feature tiles (2 output tiles x 2 k-groups, packed in the accumulators' k order) are requested now; the loads are issued in
+    // every layer (a hot line when there is nothing to fetch) so that the ring's wait counts stay compile-time constants.
+    const bool fuse = a.fuse_last != 0 && l == a.n_layers - 2;
+    f32x4 wl[2][2];
+    {
+      const int OL = a.dims[a.n_layers], ngL = (a.dims[a.n_layers - 1] + 15) >> 4, ntoL = (OL + 15) >> 4;
+#pragma unroll
+      for (int to = 0; to < 2; to++) {
+        wl[to][0] = ldfrag(a.wt_last, fuse ? (min(to, ntoL - 1) * ngL + min(p.t0, ngL - 1)) * 64 + lane : lane);
+        wl[to][1] = ldfrag(a.wt_last, fuse ? (min(to, ntoL - 1) * ngL + min(p.t1, ngL - 1)) * 64 + lane : lane);
+      }
+    }
     WavePlan pn = p;
     if (!last) pn = plan_layer(a, l + 1, wave, lane);
     {
       const int n = p.work ? p.g1 - p.g0 : 0;                    // k-groups of this wave in this layer: <= kMaxGroups
-      const int nv = last ? n : (n + kRing - 1 > kRing ? ((n + kRing - 1) & ~(kRing - 1)) : kRing);   // the last layer prefetches for nobody
-      const int nn = (!last && pn.work) ? pn.g1 - pn.g0 : 0;
+      const int nv = (last || fuse) ? n : (n + kRing - 1 > kRing ? ((n + kRing - 1) & ~(kRing - 1)) : kRing);   // the last computed layer prefetches for nobody
+      const int nn = (!last && !fuse && pn.work) ? pn.g1 - pn.g0 : 0;
       f32x4 av = *reinterpret_cast<const f32x4*>(x + 4 * (n > 0 ? p.g0 : 0));
       unroll_while(std::make_integer_sequence<int, kMaxGroups>{}, [&](auto iT) {
         constexpr int i = decltype(iT)::value;
@@ -219,8 +241,8 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restri
           const f32x4 c0 = r0[i % kRing], c1 = r1[i % kRing];
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c0[j], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j], c1[j], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(c0[j], av[j], acc0, 0, 0, 0);   // Y' = W X': weights are the A operand
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(c1[j], av[j], acc1, 0, 0, 0);
           }
           av = an;
         }
@@ -254,22 +276,62 @@ __global__ void __launch_bounds__(kMlpThreads) k_mlp_fused(const float* __restri
       }
     }
     MLP_STAMP(3 + 3 * l);
-    // epilogue: C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg
+    // epilogue. C/D layout of 16x16x4: col = lane & 15, row = (lane >> 4) * 4 + reg; with Y' = W X' the column is the batch row and the
+    // row the output feature: lane (r, q) holds features 16 t + 4 q + reg of batch row r - which is exactly what the B operand of the
+    // next layer's k-steps wants (see the fused last layer below), and 16 contiguous bytes of the output row.
+    if (fuse) {
+      // ---- the last layer from registers: Y2' = W2 Y1'. Lane (r, q) holds, for each of its two feature tiles t, the features
+      // 16 t + 4 q + reg of batch row r after bias + ELU - as a B operand that is k-step `reg` of k-group t in the packing of wt_last.
+      // A wave contributes the partial sums over ITS features; the eight waves' partials are added through LDS (split-k by wave).
+      const int OL = a.dims[a.n_layers], ntoL = (OL + 15) >> 4;
+      f32x4 a2[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+      if (cur.work) {
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+          if (half == 0 || cur.two) {
+            const int tile = half ? cur.t1 : cur.t0;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+              const int f = 16 * tile + 4 * q + reg;
+              float v = (half ? acc1[reg] : acc0[reg]) + (half ? bias1[reg] : bias0[reg]);
+              v = v > 0.0f ? v : __expf(v) - 1.0f;
+              v = f < O ? v : 0.0f;
+              a2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[0][half][reg], v, a2[0], 0, 0, 0);
+              a2[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wl[1][half][reg], v, a2[1], 0, 0, 0);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int reg = 0; reg < 4; reg++) { red[wave][reg][lane] = a2[0][reg]; red[wave][4 + reg][lane] = a2[1][reg]; }
+      lds_barrier();
+      if (wave < ntoL) {                 // wave `to` finishes output tile `to`: sum of the eight partials, bias, store
+        const float* __restrict__ BL = a.b[a.n_layers - 1];
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          float v = 0.0f;
+#pragma unroll
+          for (int ww = 0; ww < kMlpWaves; ww++) v += red[ww][4 * wave + reg][lane];
+          const int f = 16 * wave + 4 * q + reg;
+          if (f < OL && row0 + r < a.N) out[(size_t)(row0 + r) * OL + f] = v + BL[f];
+        }
+      }
+      return;
+    }
     if (cur.work && cur.part == 0) {
 #pragma unroll
       for (int half = 0; half < 2; half++) {
-        const int col = 16 * (half ? cur.t1 : cur.t0) + r;
-        if ((half == 0 || cur.two) && col < Op) {
-          const float bias = half ? bias1 : bias0;
+        const int tile = half ? cur.t1 : cur.t0;
+        if (half == 0 || cur.two) {
 #pragma unroll
           for (int reg = 0; reg < 4; reg++) {
-            const int rr = q * 4 + reg;
-            float v = (half ? acc1[reg] : acc0[reg]) + bias;
+            const int f = 16 * tile + 4 * q + reg;
+            float v = (half ? acc1[reg] : acc0[reg]) + (half ? bias1[reg] : bias0[reg]);
             if (!last) {
               v = v > 0.0f ? v : __expf(v) - 1.0f;   // ELU; v_exp_f32 (1 ulp) - 1: absolute error < 1.2e-7, no libm call in the epilogue
-              y[rr * kActLd + act_pos(col)] = col < O ? v : 0.0f;   // columns up to the next multiple of 16 feed zero weights: keep them finite
-            } else if (col < O && row0 + rr < a.N) {
-              out[(size_t)(row0 + rr) * O + col] = v;
+              y[r * kActLd + reg * kQStride + (4 * tile + q)] = f < O ? v : 0.0f;   // = act_pos(f); features up to the next multiple of 16 feed zero weights: keep them finite
+            } else if (f < O && row0 + r < a.N) {
+              out[(size_t)(row0 + r) * O + f] = v;
             }
           }
         }
@@ -317,6 +379,8 @@ struct nm_policy {
   std::vector<int> dims;
   bool fused = false, loaded = false;
   f32x4* packed = nullptr;            // fused path: packed weights of all layers
+  f32x4* packed_t = nullptr;          // the last layer in the accumulator k order (fuse_last)
+  bool fuse_last = false;
   float* bias = nullptr;              // own copy of the biases (the handle never points into caller memory)
   float* wcopy = nullptr;             // per-layer path: own copy of the weights, torch layout
   std::vector<size_t> w_off, b_off, p_off;
@@ -353,6 +417,16 @@ extern "C" int nm_policy_create(const int32_t* dims, int32_t n_layers, int32_t d
   }
   bool ok = hipMalloc((void**)&h->bias, btot * sizeof(float)) == hipSuccess;
   if (ok && h->fused) ok = hipMalloc((void**)&h->packed, ptot * sizeof(f32x4)) == hipSuccess;
+  // The last layer can take the previous layer's accumulators straight from the registers when it is narrow (<= 32 outputs: two
+  // accumulator tiles) and the previous layer is not split over k (every wave then holds finished features): no LDS round trip, no
+  // barrier, no separate phase for it. The split rule is plan_layer's.
+  if (ok && h->fused && n_layers >= 2 && dims[n_layers] <= 32) {
+    const int Kp = dims[n_layers - 2], Op = dims[n_layers - 1];
+    const int npair = ((Op + 15) / 16 + 1) / 2, ngrp = (Kp + 15) / 16;
+    const bool split = npair * 2 <= kMlpWaves && ngrp / 2 >= 4;
+    h->fuse_last = !split;
+    if (h->fuse_last) ok = hipMalloc((void**)&h->packed_t, (size_t)((dims[n_layers] + 15) / 16) * ((Op + 15) / 16) * 64 * sizeof(f32x4)) == hipSuccess;
+  }
   if (ok && !h->fused) ok = hipMalloc((void**)&h->wcopy, wtot * sizeof(float)) == hipSuccess;
   if (!ok) { nm_policy_destroy(h); return nm_policy_set_error("nm_policy_create: hipMalloc failed"); }
   *out = h;
@@ -364,6 +438,7 @@ extern "C" int nm_policy_destroy(nm_policy* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   if (h->packed) (void)hipFree(h->packed);
+  if (h->packed_t) (void)hipFree(h->packed_t);
   if (h->bias) (void)hipFree(h->bias);
   if (h->wcopy) (void)hipFree(h->wcopy);
   for (int i = 0; i < 2; i++) if (h->scratch[i]) (void)hipFree(h->scratch[i]);
@@ -383,8 +458,12 @@ extern "C" int nm_policy_load(nm_policy* h, const float* const* weights, const f
       return nm_policy_set_error("nm_policy_load: bias copy failed");
     if (h->fused) {
       const int ntile = (O + 15) / 16, ngrp = (K + 15) / 16, n = ntile * ngrp * 64;
-      hipLaunchKernelGGL(k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, s, weights[l], h->packed + h->p_off[l], O, K, ngrp, ntile);
+      hipLaunchKernelGGL(k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, s, weights[l], h->packed + h->p_off[l], O, K, ngrp, ntile, 0);
       h->args.w[l] = h->packed + h->p_off[l];
+      if (l == h->n_layers - 1 && h->fuse_last) {
+        hipLaunchKernelGGL(k_pack_weights, dim3((n + 255) / 256), dim3(256), 0, s, weights[l], h->packed_t, O, K, ngrp, ntile, 1);
+        h->args.wt_last = h->packed_t;
+      }
     } else if (hipMemcpyAsync(h->wcopy + h->w_off[l], weights[l], (size_t)O * K * sizeof(float), hipMemcpyDeviceToDevice, s) != hipSuccess) {
       return nm_policy_set_error("nm_policy_load: weight copy failed");
     }
@@ -393,6 +472,8 @@ extern "C" int nm_policy_load(nm_policy* h, const float* const* weights, const f
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_policy_load: launch failed");
   for (int l = 0; l <= h->n_layers && l <= kMaxLayers; l++) h->args.dims[l] = h->dims[l];
   h->args.n_layers = h->n_layers;
+  h->args.fuse_last = h->fuse_last ? 1 : 0;
+  if (!h->fuse_last) h->args.wt_last = h->packed;
   h->loaded = true;
   return 0;
 }
