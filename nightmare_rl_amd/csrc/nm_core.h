@@ -96,7 +96,8 @@ template <class real> struct Args {
   int* feetflags;        // [N] bits 0..5 last_contacts, bits 6..11 last_contacts_filt (env.py:92-93)
   int64_t* eplen;
   uint32_t* rngctr;
-  int* hullcache;        // [N,8] warm start of the support-vertex search (any value in range is valid)
+  int* hullcache;        // [N,8] warm start of the support-vertex search (any vertex index in range is valid); bits 16.. of entry 0: the
+                         // env's contact count at the end of the previous step (issue-priority hint, nm_set_priority), entry 7: fallback count
   // inputs
   const float* actions;  // [N,18]
   const real* cmd_u;     // [N,4] or null
