@@ -4,10 +4,10 @@ import numpy as np
 import pytest
 
 
-def crossing_states(n, rng):
-    """Airborne robots with pairs of neighbouring legs swung into each other."""
+def crossing_states(n, rng, z=0.5):
+    """Robots with pairs of neighbouring legs swung into each other: airborne (z = 0.5) or, lower, standing on the other legs."""
     qpos = np.zeros((n, 25))
-    qpos[:, 2] = 0.5
+    qpos[:, 2] = z
     qpos[:, 3] = 1.0
     qpos[:, 7:] = np.tile([0.0, -0.6, 0.4], 6) + rng.uniform(-0.1, 0.1, (n, 18))
     pairs = [(0, 1), (1, 2), (3, 4), (4, 5), (0, 1), (4, 5)]
@@ -25,9 +25,10 @@ def squeeze_actions(n, rng):
     return a
 
 
-def run_pairwise(make_dev, oracle_mod, double, steps=12, n=12):
+def run_pairwise(make_dev, oracle_mod, double, steps=12, n=12, z=0.5, count_mixed=False):
     rng = np.random.default_rng(11)
-    qpos, qvel = crossing_states(n, rng)
+    qpos, qvel = crossing_states(n, rng, z)
+    nmixed = 0
     dev = make_dev(n, double)
     ora = oracle_mod.OracleEnv(n, seed=0)
     oerr, serr, ncontact = [], 0.0, 0
@@ -42,13 +43,17 @@ def run_pairwise(make_dev, oracle_mod, double, steps=12, n=12):
         obs, rew, done = dev.step(a)
         for i in range(n):
             d = ora.data(i)
-            ncontact += sum(1 for c in range(d.ncon) if d.con_body1[c] > 0)
+            npair = sum(1 for c in range(d.ncon) if d.con_body1[c] > 0)
+            ncontact += npair
+            nmixed += int(npair > 0 and d.ncon > npair)
         oerr.append(np.abs(obs.astype(np.float64) - oobs).max(axis=1))
         assert (done == odone).all()
         qpos, qvel, qw = ora.get_state()
         q2, v2, _ = dev.get_state()
         nd = odone == 0
         serr = max(serr, np.abs(q2[nd] - qpos[nd]).max(), np.abs(v2[nd] - qvel[nd]).max())
+    if count_mixed:
+        return np.concatenate(oerr), serr, ncontact, nmixed
     return np.concatenate(oerr), serr, ncontact
 
 
@@ -101,3 +106,11 @@ def test_device_code_fp32_within_tolerance_with_leg_contacts(oracle_mod):
     oerr, serr, ncontact = run_pairwise(EmulDev, oracle_mod, double=False, steps=12, n=48)
     assert ncontact >= 40
     assert oerr.max() <= 1e-4 and np.median(oerr) < 5e-6, (np.median(oerr), oerr.max())      # no allowance: MPR runs in fp64 in both builds
+
+
+def test_device_code_with_floor_and_leg_contacts_in_the_same_env(oracle_mod):
+    """Tibia-tibia contacts in an env that also stands on the floor: the pair contacts follow the floor contacts in the list, and the
+    floor contacts' frame / first body are only filled in (floor_frames) when such a general path runs. fp64 device code == oracle."""
+    oerr, serr, ncontact, nmixed = run_pairwise(EmulDev, oracle_mod, double=True, steps=10, n=24, z=0.07, count_mixed=True)
+    assert nmixed >= 10, (ncontact, nmixed)
+    assert oerr.max() < 1e-6 and serr < 1e-8, (oerr.max(), serr)
