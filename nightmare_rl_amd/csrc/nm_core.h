@@ -159,7 +159,8 @@ template <class real> struct Sh {
 #endif
   int ncon, nwarn, it_pgs, it_noslip, anypair;
   int nhop;
-  int ntog;                       // [env 0 of a wave] substeps of this step whose constraint stage took both envs in one pass (debug buffer only)
+  int ntog;                       // debug buffer only. [env 0 of a wave] substeps of this step whose constraint stage took both envs in one pass;
+                                  // [env 1] contact counts of the first substep, n0 * 64 + n1
   real eact[kNU], epact[kNU], epdv[kNU];  // this step's clipped actions, last step's actions and joint velocities (epilogue inputs)
   real ecmd[4], eepsum[kNREW];    // env buffers fetched at load time for the epilogue: commands, episode sums
   int eplen_lo, eplen_hi;         // episode_length_buf[env] (int64) as it was before this step
@@ -381,18 +382,20 @@ template <class real> NM_FN V<real> legsum(const V<real>& x, const VB& isleg) { 
 template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Model<real>& M, bool last) {
   typedef V<real> vr;
   real* lds = reinterpret_cast<real*>(&w.e[0]);
-  const Grp<real, G> gp;
-  const V<int> leg = gp.leg, eo = gp.eo;
-  const VB isleg = gp.sub < V<int>(6);   // NOT `& gact`: the lane groups beyond G must compute env G-1 again, exactly (see the stores below)
+  // Lane groups of 8: group g works on env g % G; groups [0, G) factor M, groups [G, 2G) factor M + h*kv*I (implicitfast) - the two
+  // factorisations are the same instructions on different lanes, not two passes. Everything before the factorisation does not depend
+  // on the pass, so the groups of an env hold exact duplicates there; groups beyond 2G repeat the first 2G.
+  static_assert((G & (G - 1)) == 0 && 2 * G <= 8, "lane groups: G envs x 2 factorisations");
+  const V<int> lane0 = opaque_lane();
+  const V<int> sub = lane0 & 7, grp = lane0 >> 3;
+  const V<int> leg = vmin(sub, V<int>(5)), eo = (grp & (G - 1)) * (int)(sizeof(Sh<real>) / sizeof(real));
+  const VB pass1 = (grp & G) != 0;
+  const VB isleg = sub < V<int>(6);
 #define LDG(field, i) ldsv(lds, eo + (NM_OFS(field) + (i)))
-  // Stores of this stage are NOT masked: the lanes outside `isleg` / `lead` hold exact duplicates (sub 6, 7 compute leg 5 again, the
-  // lane groups beyond G alias env G-1, per-env values are computed by all eight lanes of a group), so they write the same value to
+  // Stores of this stage are NOT masked: the lanes outside the legs / the first lane of a group hold exact duplicates (sub 6, 7 compute
+  // leg 5 again, per-env values are computed by all eight lanes of every group of the env), so they write the same value to
   // the same address. A masked store is an exec-mask branch: 70 of them cut this stage into ~45-instruction scheduling regions.
-#ifdef NM_MASKED_A     // A/B only
-  const VB st_all = gp.lead, st_leg = gp.isleg;
-#else
   const VB st_all = VB(true), st_leg = VB(true);
-#endif
 #define STG(field, i, val) stsv(lds, eo + (NM_OFS(field) + (i)), val, st_all)
 #define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
 #define STL(field, idx, val) stsv(lds, eo + (idx) + NM_OFS(field), val, st_leg)
@@ -615,12 +618,21 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
   }
   wave_sync();
 
-  // ---- block factorisations: M (pass 0) and M + h*kv*I on the actuated dofs (pass 1, implicitfast)
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
+  // ---- block factorisations: M (lane groups [0, G)) and M + h*kv*I on the actuated dofs (groups [G, 2G), implicitfast), at once.
+  // The second factor lives kFacH words behind the first in the env image; its Schur complement is staged in the (now free) leg
+  // staging area, and what only the first factorisation feeds (qfrc_smooth, qacc_smooth) is written by the other groups to a
+  // junk row of that area.
+  {
     sched_fence();
+    constexpr int kFacH = NM_OFS(MinvH) - NM_OFS(Minv);
+    static_assert(NM_OFS(WH) - NM_OFS(W) == kFacH && NM_OFS(LbH) - NM_OFS(Lb) == kFacH && NM_OFS(DbiH) - NM_OFS(Dbi) == kFacH, "factor blocks");
+    static_assert(kNLEG * 66 >= 36 + 24 + 24, "leg staging area holds the second Schur complement and the junk rows");
+    const V<int> eoF = eo + sel(pass1, V<int>(kFacH), V<int>(0));
+    const V<int> eoS = eo + sel(pass1, V<int>(NM_OFS(legtmp)), V<int>(NM_OFS(sc)));
+    const V<int> eoQ = eo + sel(pass1, V<int>(NM_OFS(legtmp) + 36), V<int>(NM_OFS(qfs)));
+    const V<int> eoA = eo + sel(pass1, V<int>(NM_OFS(legtmp) + 60), V<int>(NM_OFS(qas)));
     vr Mh[6];
-    real dg = pass ? M.h * M.kv : real(0);
+    const vr dg = sel(pass1, vr(M.h * M.kv), vr(real(0)));
     Mh[0] = Ml[0] + dg; Mh[1] = Ml[1]; Mh[2] = Ml[2]; Mh[3] = Ml[3] + dg; Mh[4] = Ml[4]; Mh[5] = Ml[5] + dg;
     vr Mi[6], W[3][6];
     ldl3(Mi, Mh, real(1));
@@ -630,38 +642,37 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
       ldl3_solve(r3, Mi, col);
       W[0][j] = r3[0]; W[1][j] = r3[1]; W[2][j] = r3[2];
     }
-    const int oMinv = pass ? NM_OFS(MinvH) : NM_OFS(Minv), oW = pass ? NM_OFS(WH) : NM_OFS(W);
-    const int oL = pass ? NM_OFS(LbH) : NM_OFS(Lb), oD = pass ? NM_OFS(DbiH) : NM_OFS(Dbi);
 #pragma unroll
-    for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 6 + (oMinv + j), Mi[j], st_leg);
+    for (int j = 0; j < 6; j++) stsv(lds, eoF + leg * 6 + (NM_OFS(Minv) + j), Mi[j], st_leg);
 #pragma unroll
     for (int k = 0; k < 3; k++)
 #pragma unroll
-      for (int j = 0; j < 6; j++) stsv(lds, eo + leg * 18 + (oW + 6 * k + j), W[k][j], st_leg);
+      for (int j = 0; j < 6; j++) stsv(lds, eoF + leg * 18 + (NM_OFS(W) + 6 * k + j), W[k][j], st_leg);
     // Schur complement of the leg blocks (upper triangle, row-major in LDS)
 #pragma unroll
     for (int i = 0; i < 6; i++)
 #pragma unroll
       for (int j = i; j < 6; j++) {
         vr cij = Mlb[0][i] * W[0][j] + Mlb[1][i] * W[1][j] + Mlb[2][i] * W[2][j];
-        STG(sc, 6 * i + j, LDG(mbb, 6 * i + j) - legsum<real>(cij, isleg));
+        stsv(lds, eoS + (6 * i + j), LDG(mbb, 6 * i + j) - legsum<real>(cij, isleg), st_all);
       }
     wave_sync();
     vr L[15], Di[6];
-    ldl6([&](int r, int c) { return LDG(sc, 6 * r + c); }, L, Di, real(1));
+    ldl6([&](int r, int c) { return ldsv(lds, eoS + (6 * r + c)); }, L, Di, real(1));
 #pragma unroll
-    for (int j = 0; j < 15; j++) stsv(lds, eo + (oL + j), L[j], st_all);
+    for (int j = 0; j < 15; j++) stsv(lds, eoF + (NM_OFS(Lb) + j), L[j], st_all);
 #pragma unroll
-    for (int j = 0; j < 6; j++) stsv(lds, eo + (oD + j), Di[j], st_all);
-    if (pass == 0) {
-      // ---- servo forces, qfrc_smooth, qacc_smooth = M^-1 qfrc_smooth (block solve in the leg layout)
+    for (int j = 0; j < 6; j++) stsv(lds, eoF + (NM_OFS(Dbi) + j), Di[j], st_all);
+    {
+      // ---- servo forces, qfrc_smooth, qacc_smooth = M^-1 qfrc_smooth (block solve in the leg layout); the groups that hold the
+      // factor of M write the results, the others a junk row
       vr y[3], t[3];
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         vr ctrl = LDL(ctrl, leg * 3 + k), qd = LDL(qvel, leg * 3 + (6 + k));
         ctrl = vmin(vmax(ctrl, vr(-M.ctrl_max)), vr(M.ctrl_max));
         y[k] = M.kv * ctrl - M.kv * qd - cl[k];
-        STL(qfs, leg * 3 + (6 + k), y[k]);
+        stsv(lds, eoQ + leg * 3 + (6 + k), y[k], st_leg);
       }
       ldl3_solve(t, Mi, y);
       vr xb[6];
@@ -669,17 +680,17 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
       for (int j = 0; j < 6; j++) {
         vr wy = W[0][j] * y[0] + W[1][j] * y[1] + W[2][j] * y[2];
         xb[j] = -cbias[j] - legsum<real>(wy, isleg);
-        STG(qfs, j, -cbias[j]);
+        stsv(lds, eoQ + j, -cbias[j], st_all);
       }
       ldl6_solve(L, Di, xb);
 #pragma unroll
-      for (int j = 0; j < 6; j++) STG(qas, j, xb[j]);
+      for (int j = 0; j < 6; j++) stsv(lds, eoA + j, xb[j], st_all);
 #pragma unroll
       for (int k = 0; k < 3; k++) {
         vr x = t[k];
 #pragma unroll
         for (int j = 0; j < 6; j++) x = x - W[k][j] * xb[j];
-        STL(qas, leg * 3 + (6 + k), x);
+        stsv(lds, eoA + leg * 3 + (6 + k), x, st_leg);
       }
     }
   }
@@ -1641,6 +1652,13 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   vr cp[3] = {ldsv(rb, ho + (c * 3 + oLeg)), ldsv(rb, ho + (c * 3 + (oLeg + 1))), ldsv(rb, ho + (c * 3 + (oLeg + 2)))};
   vr dist = ldsv(rb, ho + (c + (oLeg + 6 * kMaxConBig)));
   V<int> L = ldsv(ib, hoi + (c + oCleg));
+  {  // a half whose env has no contact at all (the pass then runs for the other env alone) reads a stale record as contact 0: every
+     // lane of it is inactive, but what it computes must stay finite (0 * NaN would switch off that half's solver exits)
+    const VB any = nconv > 0;
+    cp[0] = sel(any, cp[0], vr(real(0))); cp[1] = sel(any, cp[1], vr(real(0))); cp[2] = sel(any, cp[2], vr(real(0)));
+    dist = sel(any, dist, vr(real(0)));
+    L = sel(any, L, V<int>(-1));
+  }
   const VB onleg = L >= 0;
   const V<int> Lc = vmax(L, V<int>(0));
   const V<int> q4 = hl & 3;
@@ -2514,7 +2532,8 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
   if constexpr (G == 2) {
     const int n0 = uniform(w.e[0].ncon), n1 = uniform(w.e[1].ncon);
     nm_set_priority(n0 + n1);      // (counting the support search's hops / fallbacks as well measured no better: 68.7 vs 68.8-69.4 us)
-    together = n0 >= 1 && n1 >= 1 && n0 <= kMaxCon2 && n1 <= kMaxCon2 && uniform(w.e[0].anypair) == 0 && uniform(w.e[1].anypair) == 0 && !(ablate & 32);
+    together = n0 + n1 >= 1 && n0 <= kMaxCon2 && n1 <= kMaxCon2 && uniform(w.e[0].anypair) == 0 && uniform(w.e[1].anypair) == 0 && !(ablate & 32);
+    if (!last) w.e[1].ntog = n0 * 64 + n1;   // debug buffer only: the first substep's contact counts
     if (together) {
 #ifdef NM_EMUL
       nm_emul_together() += 1;

@@ -135,6 +135,9 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
     real* d = As.dbg + (size_t)(wave * G) * nm::kDbgN + 250;
     d[0] = (real)(unsigned)(t_start & 0xFFFFFF); d[1] = (real)(unsigned)((t_start >> 24) & 0xFFFFFF);
     d[2] = (real)(unsigned)(t_end & 0xFFFFFF); d[3] = (real)(unsigned)((t_end >> 24) & 0xFFFFFF);
+    // where the wave ran: HW_ID (hwreg 4: wave[3:0] simd[5:4] pipe[7:6] cu[11:8] sh[12] se[15:13]) and XCC_ID (hwreg 20)
+    d[4] = (real)(__builtin_amdgcn_s_getreg(4 | (0 << 6) | (15 << 11)) & 0xFFFF);
+    d[5] = (real)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 0xF);
   }
   if (As.physics_only) return;
   // The wave that finishes last closes the step (what used to be a second launch). What it needs from the others went through
