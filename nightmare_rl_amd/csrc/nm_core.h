@@ -2340,52 +2340,56 @@ template <class real> NM_FN void stage_constraint(Sh<real>& sh, real* jrow, cons
 template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const Model<real>& M) {
   typedef V<real> vr;
   real* lds = reinterpret_cast<real*>(&w.e[0]);
-  const Grp<real, G> gp;
-  const V<int> leg = gp.leg, eo = gp.eo;
-  const VB isleg = gp.sub < V<int>(6);   // as in stage A: every lane group computes (and stores) its env's values, duplicates included
+  // lane groups as in stage A: group g works on env g % G; groups [0, G) solve with the factor of M (qacc, for the warm start and
+  // mj_checkAcc), groups [G, 2G) with the factor of M + h kv I (the implicitfast velocity update) - one pass on different lanes. What
+  // a group's solve does not feed is stored to a junk row of the leg staging area (free here: the contact list is spent).
+  const V<int> lane0 = opaque_lane();
+  const V<int> sub = lane0 & 7, grp = lane0 >> 3;
+  const V<int> leg = vmin(sub, V<int>(5)), eo = (grp & (G - 1)) * (int)(sizeof(Sh<real>) / sizeof(real));
+  const VB pass1 = (grp & G) != 0;
+  const VB isleg = sub < V<int>(6);   // as in stage A: every lane group computes (and stores) its env's values, duplicates included
 #define LDG(field, i) ldsv(lds, eo + (NM_OFS(field) + (i)))
 #define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
-  vr qacc_l[3], qint_l[3], qacc_b[6], qint_b[6];
-#pragma unroll
-  for (int pass = 0; pass < 2; pass++) {
-    // pass 0: qacc = qacc_smooth + M^-1 qfrc_constraint ; pass 1: (M + h kv I) qacc_int = qfrc_smooth + qfrc_constraint
-    const int oMinv = pass ? NM_OFS(MinvH) : NM_OFS(Minv), oW = pass ? NM_OFS(WH) : NM_OFS(W);
-    const int oL = pass ? NM_OFS(LbH) : NM_OFS(Lb), oD = pass ? NM_OFS(DbiH) : NM_OFS(Dbi);
+  constexpr int kFacH = NM_OFS(MinvH) - NM_OFS(Minv);
+  static_assert(NM_OFS(WH) - NM_OFS(W) == kFacH && NM_OFS(LbH) - NM_OFS(Lb) == kFacH && NM_OFS(DbiH) - NM_OFS(Dbi) == kFacH, "factor blocks");
+  static_assert(kNLEG * 66 >= 24 + 28 + 24, "leg staging area holds the junk rows");
+  const V<int> eoF = eo + sel(pass1, V<int>(kFacH), V<int>(0));
+  vr xl[3], xb[6];     // groups [0, G): M^-1 qfrc_constraint ; groups [G, 2G): (M + h kv I)^-1 (qfrc_smooth + qfrc_constraint)
+  {
     vr y[3], t[3], Mi[6];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-      y[k] = LDL(qfc, leg * 3 + (6 + k));
-      if (pass) y[k] = y[k] + LDL(qfs, leg * 3 + (6 + k));
-    }
+    for (int k = 0; k < 3; k++) y[k] = LDL(qfc, leg * 3 + (6 + k)) + sel(pass1, LDL(qfs, leg * 3 + (6 + k)), vr(real(0)));
 #pragma unroll
-    for (int j = 0; j < 6; j++) Mi[j] = ldsv(lds, eo + leg * 6 + (oMinv + j));
+    for (int j = 0; j < 6; j++) Mi[j] = ldsv(lds, eoF + leg * 6 + (NM_OFS(Minv) + j));
     ldl3_solve(t, Mi, y);
-    vr xb[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
-      vr wy = ldsv(lds, eo + leg * 18 + (oW + j)) * y[0] + ldsv(lds, eo + leg * 18 + (oW + 6 + j)) * y[1] +
-              ldsv(lds, eo + leg * 18 + (oW + 12 + j)) * y[2];
-      xb[j] = LDG(qfc, j) - legsum<real>(wy, isleg);
-      if (pass) xb[j] = xb[j] + LDG(qfs, j);
+      vr wy = ldsv(lds, eoF + leg * 18 + (NM_OFS(W) + j)) * y[0] + ldsv(lds, eoF + leg * 18 + (NM_OFS(W) + 6 + j)) * y[1] +
+              ldsv(lds, eoF + leg * 18 + (NM_OFS(W) + 12 + j)) * y[2];
+      xb[j] = LDG(qfc, j) - legsum<real>(wy, isleg) + sel(pass1, LDG(qfs, j), vr(real(0)));
     }
     {
       vr L[15], Di[6];
 #pragma unroll
-      for (int j = 0; j < 15; j++) L[j] = ldsv(lds, eo + (oL + j));
+      for (int j = 0; j < 15; j++) L[j] = ldsv(lds, eoF + (NM_OFS(Lb) + j));
 #pragma unroll
-      for (int j = 0; j < 6; j++) Di[j] = ldsv(lds, eo + (oD + j));
+      for (int j = 0; j < 6; j++) Di[j] = ldsv(lds, eoF + (NM_OFS(Dbi) + j));
       ldl6_solve(L, Di, xb);
     }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
       vr x = t[k];
 #pragma unroll
-      for (int j = 0; j < 6; j++) x = x - ldsv(lds, eo + leg * 18 + (oW + 6 * k + j)) * xb[j];
-      if (pass) qint_l[k] = x; else qacc_l[k] = x + LDL(qas, leg * 3 + (6 + k));
+      for (int j = 0; j < 6; j++) x = x - ldsv(lds, eoF + leg * 18 + (NM_OFS(W) + 6 * k + j)) * xb[j];
+      xl[k] = x;
     }
-#pragma unroll
-    for (int j = 0; j < 6; j++) { if (pass) qint_b[j] = xb[j]; else qacc_b[j] = xb[j] + LDG(qas, j); }
   }
+  vr qacc_l[3], qacc_b[6];       // meaningful in groups [0, G)
+#pragma unroll
+  for (int k = 0; k < 3; k++) qacc_l[k] = xl[k] + LDL(qas, leg * 3 + (6 + k));
+#pragma unroll
+  for (int j = 0; j < 6; j++) qacc_b[j] = xb[j] + LDG(qas, j);
+  const vr* qint_l = xl; const vr* qint_b = xb;   // meaningful in groups [G, 2G)
   // mj_checkAcc, per env
   VB badl = (visbad(qacc_l[0]) | visbad(qacc_l[1]) | visbad(qacc_l[2])) & isleg;
 #pragma unroll
@@ -2425,20 +2429,23 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
     jq[k] = LDL(qpos, leg * 3 + (7 + k)) + M.h * jv[k];
   }
   wave_sync();
+  const V<int> eoV = eo + sel(pass1, V<int>(NM_OFS(qvel)), V<int>(NM_OFS(legtmp)));
+  const V<int> eoP = eo + sel(pass1, V<int>(NM_OFS(qpos)), V<int>(NM_OFS(legtmp) + 24));
+  const V<int> eoW = eo + sel(pass1, V<int>(NM_OFS(legtmp) + 52), V<int>(NM_OFS(warm)));
 #pragma unroll
   for (int j = 0; j < 6; j++) {
-    stsv(lds, eo + (NM_OFS(qvel) + j), nv[j], okb);
-    stsv(lds, eo + (NM_OFS(warm) + j), qacc_b[j], okb);
+    stsv(lds, eoV + j, nv[j], okb);
+    stsv(lds, eoW + j, qacc_b[j], okb);
   }
 #pragma unroll
-  for (int j = 0; j < 3; j++) stsv(lds, eo + (NM_OFS(qpos) + j), np_[j], okb);
+  for (int j = 0; j < 3; j++) stsv(lds, eoP + j, np_[j], okb);
 #pragma unroll
-  for (int j = 0; j < 4; j++) stsv(lds, eo + (NM_OFS(qpos) + 3 + j), nq[j], okb);
+  for (int j = 0; j < 4; j++) stsv(lds, eoP + (3 + j), nq[j], okb);
 #pragma unroll
   for (int k = 0; k < 3; k++) {
-    stsv(lds, eo + leg * 3 + (NM_OFS(qvel) + 6 + k), jv[k], okl);
-    stsv(lds, eo + leg * 3 + (NM_OFS(qpos) + 7 + k), jq[k], okl);
-    stsv(lds, eo + leg * 3 + (NM_OFS(warm) + 6 + k), qacc_l[k], okl);
+    stsv(lds, eoV + leg * 3 + (6 + k), jv[k], okl);
+    stsv(lds, eoP + leg * 3 + (7 + k), jq[k], okl);
+    stsv(lds, eoW + leg * 3 + (6 + k), qacc_l[k], okl);
   }
   wave_sync();
   // bad envs (rare): mj_resetData, then one free-fall step from qpos0 (no contacts at z0, ctrl = 0 -> qacc = (0,0,-g,0...))
