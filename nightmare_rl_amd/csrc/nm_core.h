@@ -433,10 +433,15 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
 #pragma unroll
   for (int j = 0; j < 6; j++) STG(wv, j, vb[j]);
 
-  // ---- forward pass down the chain: pose, motion vector, spatial inertia, velocity, bias acceleration, body force
+  // ---- forward pass down the chain. Serial in the link (every lane walks all three links of its leg): pose, motion vector,
+  // velocity and bias acceleration. What then needs only ONE link's pose and velocities - spatial inertia about the base origin,
+  // I a + v x* I v - is done once, by the lane group whose role is that link (role = group / G: links 0, 1, 2, and 2 again), instead
+  // of three times by everybody: each lane keeps the state of its own link as the walk passes it.
+  const V<int> mylink = vmin(grp >> (G == 1 ? 0 : (G == 2 ? 1 : 2)), V<int>(2));
   vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
   {
     vr Rp[9], pp[3], vpar[6], apar[6];
+    vr cR[9], cpos[3], cS[6], cv[6], ca[6];      // this lane's link: pose, motion vector, velocity, bias acceleration
 #pragma unroll
     for (int k = 0; k < 9; k++) Rp[k] = Rb[k];
     pp[0] = pp[1] = pp[2] = vr(real(0));
@@ -485,47 +490,73 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
         for (int j = 0; j < 3; j++) STL(colp, (leg + 1) * 3 + j, pos[j]);
       }
       sched_fence();
-      vr S[6], I10[10];
+      vr S[6];
       S[0] = aw[0]; S[1] = aw[1]; S[2] = aw[2];
       cross3(S + 3, pos, aw);  // motion vector about the base origin: [a; r x a]
-      {
-        vr ipos[3] = {ldsv(M.legc, cb + 15), ldsv(M.legc, cb + 16), ldsv(M.legc, cb + 17)};
-        vr Ib[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) Ib[j] = ldsv(M.legc, cb + 18 + j);
-        vr mass = ldsv(M.legc, cb + 24);
-        vr d[3];
-        matvec3(t3, R, ipos);
-        d[0] = pos[0] + t3[0]; d[1] = pos[1] + t3[1]; d[2] = pos[2] + t3[2];
-        spatial_inertia(I10, R, Ib, d, mass, real(0));
-        mcom[0] += mass * d[0]; mcom[1] += mass * d[1]; mcom[2] += mass * d[2];
-      }
-      // RNE forward: velocity, bias acceleration, body force
-      vr f[6];
-      {
-        vr Sd[6], t6[6], u6[6];
+      {  // RNE forward: velocity and bias acceleration of this link
+        vr Sd[6];
         cross_motion(Sd, vpar, S);
 #pragma unroll
         for (int j = 0; j < 6; j++) {
           vpar[j] = vpar[j] + S[j] * qd;
           apar[j] = apar[j] + Sd[j] * qd;
         }
-        inert_mul(t6, I10, apar);
-        inert_mul(u6, I10, vpar);
-        cross_force(f, vpar, u6);
+      }
+      if (k == 0) {
+#pragma unroll
+        for (int j = 0; j < 9; j++) cR[j] = R[j];
+#pragma unroll
+        for (int j = 0; j < 3; j++) cpos[j] = pos[j];
+#pragma unroll
+        for (int j = 0; j < 6; j++) { cS[j] = S[j]; cv[j] = vpar[j]; ca[j] = apar[j]; }
+      } else {
+        const VB mine = mylink == k;
+#pragma unroll
+        for (int j = 0; j < 9; j++) cR[j] = sel(mine, R[j], cR[j]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) cpos[j] = sel(mine, pos[j], cpos[j]);
+#pragma unroll
+        for (int j = 0; j < 6; j++) { cS[j] = sel(mine, S[j], cS[j]); cv[j] = sel(mine, vpar[j], cv[j]); ca[j] = sel(mine, apar[j], ca[j]); }
+      }
+#pragma unroll
+      for (int j = 0; j < 9; j++) Rp[j] = R[j];
+      pp[0] = pos[0]; pp[1] = pos[1]; pp[2] = pos[2];
+    }
+    sched_fence();
+    {  // this lane's link: spatial inertia, body force; parked for the backward pass
+      const V<int> cbm = leg * kLegN + mylink * kLinkN;
+      vr I10[10], f[6];
+      {
+        vr ipos[3] = {ldsv(M.legc, cbm + 15), ldsv(M.legc, cbm + 16), ldsv(M.legc, cbm + 17)};
+        vr Ib[6];
+#pragma unroll
+        for (int j = 0; j < 6; j++) Ib[j] = ldsv(M.legc, cbm + 18 + j);
+        vr mass = ldsv(M.legc, cbm + 24);
+        vr d[3], t3[3];
+        matvec3(t3, cR, ipos);
+        d[0] = cpos[0] + t3[0]; d[1] = cpos[1] + t3[1]; d[2] = cpos[2] + t3[2];
+        spatial_inertia(I10, cR, Ib, d, mass, real(0));
+        mcom[0] = mass * d[0]; mcom[1] = mass * d[1]; mcom[2] = mass * d[2];
+      }
+      {
+        vr t6[6], u6[6];
+        inert_mul(t6, I10, ca);
+        inert_mul(u6, I10, cv);
+        cross_force(f, cv, u6);
 #pragma unroll
         for (int j = 0; j < 6; j++) f[j] = f[j] + t6[j];
       }
-      const V<int> o = slot + k * kLinkTmp;
+      const V<int> o = slot + mylink * kLinkTmp;
 #pragma unroll
-      for (int j = 0; j < 6; j++) STL(legtmp, o + j, S[j]);
+      for (int j = 0; j < 6; j++) STL(legtmp, o + j, cS[j]);
 #pragma unroll
       for (int j = 0; j < 10; j++) STL(legtmp, o + (6 + j), I10[j]);
 #pragma unroll
       for (int j = 0; j < 6; j++) STL(legtmp, o + (16 + j), f[j]);
+      if (last) {   // m d summed over the legs, per link: the subtree COM below adds the three links up
 #pragma unroll
-      for (int j = 0; j < 9; j++) Rp[j] = R[j];
-      pp[0] = pos[0]; pp[1] = pos[1]; pp[2] = pos[2];
+        for (int j = 0; j < 3; j++) stsv(lds, eo + mylink * 3 + (NM_OFS(sc) + j), legsum<real>(mcom[j], isleg), st_all);
+      }
     }
   }
   wave_sync();
@@ -575,7 +606,7 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
     if (last) {  // subtree COM (relative to the base origin) -> cvel[1] as MuJoCo reports it (about the COM)
       vr cr[3], t[3];
 #pragma unroll
-      for (int j = 0; j < 3; j++) cr[j] = (M.basec[9] * d[j] + legsum<real>(mcom[j], isleg)) / M.total_mass;
+      for (int j = 0; j < 3; j++) cr[j] = (M.basec[9] * d[j] + (LDG(sc, j) + LDG(sc, 3 + j) + LDG(sc, 6 + j))) / M.total_mass;
       cross3(t, vb, cr);
 #pragma unroll
       for (int j = 0; j < 3; j++) { STG(cvb, j, vb[j]); STG(cvb, 3 + j, vb[3 + j] + t[j]); }
