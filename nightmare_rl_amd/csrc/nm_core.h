@@ -65,6 +65,7 @@ template <class real> struct Model {
   real footc[kNLEG * 4];       // foot site pos (tibia frame) + radius
   real qpos0[kNQ];
   int maxnbr;
+  int link_rot_id[3];          // link k of every leg has body_quat = 1: its frame is its parent's, rotated by the joint only
   real total_mass;
   real h, kv, ctrl_max, grav, mu;
   real solref_K, solref_B, si_d0, si_dmax, si_width, si_mid, si_power;
@@ -436,8 +437,10 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
   // ---- forward pass down the chain. Serial in the link (every lane walks all three links of its leg): pose, motion vector,
   // velocity and bias acceleration. What then needs only ONE link's pose and velocities - spatial inertia about the base origin,
   // I a + v x* I v - is done once, by the lane group whose role is that link (role = group / G: links 0, 1, 2, and 2 again), instead
-  // of three times by everybody: each lane keeps the state of its own link as the walk passes it.
-  const V<int> mylink = vmin(grp >> (G == 1 ? 0 : (G == 2 ? 1 : 2)), V<int>(2));
+  // of three times by everybody: each lane keeps the state of its own link as the walk passes it. The fourth role does the same
+  // arithmetic for the BASE body (pose Rb at the origin, velocity vb, bias acceleration ab, constants from M.basec).
+  const V<int> mylink = (grp >> (G == 1 ? 0 : (G == 2 ? 1 : 2))) & 3;      // role: link 0, 1, 2 of the lane's leg, or 3 = the base body
+  const VB isbase = mylink == 3;
   vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
   {
     vr Rp[9], pp[3], vpar[6], apar[6];
@@ -462,10 +465,15 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
         vr ax[3] = {ldsv(M.legc, cb + 12), ldsv(M.legc, cb + 13), ldsv(M.legc, cb + 14)};
         vr R0[9];
         {
-          vr bR[9];
+          if (uniform(M.link_rot_id[k])) {   // the link frame is not rotated against its parent's (femur, tibia): Rp * 1
 #pragma unroll
-          for (int j = 0; j < 9; j++) bR[j] = ldsv(M.legc, cb + 3 + j);
-          matmul3(R0, Rp, bR);
+            for (int j = 0; j < 9; j++) R0[j] = Rp[j];
+          } else {
+            vr bR[9];
+#pragma unroll
+            for (int j = 0; j < 9; j++) bR[j] = ldsv(M.legc, cb + 3 + j);
+            matmul3(R0, Rp, bR);
+          }
         }
         matvec3(aw, R0, ax);
         vr s, co;
@@ -502,13 +510,13 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
           apar[j] = apar[j] + Sd[j] * qd;
         }
       }
-      if (k == 0) {
+      if (k == 0) {   // roles 1, 2 overwrite this below; role 3 (base) keeps the base's own state
 #pragma unroll
-        for (int j = 0; j < 9; j++) cR[j] = R[j];
+        for (int j = 0; j < 9; j++) cR[j] = sel(isbase, Rb[j], R[j]);
 #pragma unroll
-        for (int j = 0; j < 3; j++) cpos[j] = pos[j];
+        for (int j = 0; j < 3; j++) cpos[j] = sel(isbase, vr(real(0)), pos[j]);
 #pragma unroll
-        for (int j = 0; j < 6; j++) { cS[j] = S[j]; cv[j] = vpar[j]; ca[j] = apar[j]; }
+        for (int j = 0; j < 6; j++) { cS[j] = S[j]; cv[j] = sel(isbase, vb[j], vpar[j]); ca[j] = sel(isbase, ab[j], apar[j]); }
       } else {
         const VB mine = mylink == k;
 #pragma unroll
@@ -524,7 +532,8 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
     }
     sched_fence();
     {  // this lane's link: spatial inertia, body force; parked for the backward pass
-      const V<int> cbm = leg * kLegN + mylink * kLinkN;
+      static_assert(offsetof(Model<real>, basec) == offsetof(Model<real>, legc) + sizeof(real) * kNLEG * kLegN, "basec follows legc");
+      const V<int> cbm = sel(isbase, V<int>(kNLEG * kLegN - 15), leg * kLegN + mylink * kLinkN);   // base: ipos Ibody mass = basec[0..9]
       vr I10[10], f[6];
       {
         vr ipos[3] = {ldsv(M.legc, cbm + 15), ldsv(M.legc, cbm + 16), ldsv(M.legc, cbm + 17)};
@@ -546,7 +555,8 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
 #pragma unroll
         for (int j = 0; j < 6; j++) f[j] = f[j] + t6[j];
       }
-      const V<int> o = slot + mylink * kLinkTmp;
+      // links: the leg's staging slot; base: words 9..30 of the (still unused) Schur-complement buffer
+      const V<int> o = sel(isbase, V<int>(NM_OFS(sc) + 9 - NM_OFS(legtmp)), slot + mylink * kLinkTmp);
 #pragma unroll
       for (int j = 0; j < 6; j++) STL(legtmp, o + j, cS[j]);
 #pragma unroll
@@ -597,13 +607,13 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
   // ---- base: own inertia/force + legs
   vr Icb[10], cbias[6];
   {
-    vr Ib10[10];
-    vr ipos[3] = {vr(M.basec[0]), vr(M.basec[1]), vr(M.basec[2])};
-    vr Ibody[6] = {vr(M.basec[3]), vr(M.basec[4]), vr(M.basec[5]), vr(M.basec[6]), vr(M.basec[7]), vr(M.basec[8])};
-    vr d[3];
-    matvec3(d, Rb, ipos);
-    spatial_inertia(Ib10, Rb, Ibody, d, vr(M.basec[9]), real(0));
+    vr Ib10[10];     // spatial inertia and body force of the base: computed by the base-role lane groups in the forward pass
+#pragma unroll
+    for (int j = 0; j < 10; j++) Ib10[j] = LDG(sc, 15 + j);
     if (last) {  // subtree COM (relative to the base origin) -> cvel[1] as MuJoCo reports it (about the COM)
+      vr ipos[3] = {vr(M.basec[0]), vr(M.basec[1]), vr(M.basec[2])};
+      vr d[3];
+      matvec3(d, Rb, ipos);
       vr cr[3], t[3];
 #pragma unroll
       for (int j = 0; j < 3; j++) cr[j] = (M.basec[9] * d[j] + (LDG(sc, j) + LDG(sc, 3 + j) + LDG(sc, 6 + j))) / M.total_mass;
@@ -612,12 +622,9 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
       for (int j = 0; j < 3; j++) { STG(cvb, j, vb[j]); STG(cvb, 3 + j, vb[3 + j] + t[j]); }
       STG(bh, 0, LDG(qpos, 2) + d[2]);   // z of the base body's COM
     }
-    vr fb[6], t6[6], u6[6], w6[6];
-    inert_mul(t6, Ib10, ab);
-    inert_mul(u6, Ib10, vb);
-    cross_force(w6, vb, u6);
+    vr fb[6];
 #pragma unroll
-    for (int j = 0; j < 6; j++) fb[j] = t6[j] + w6[j] + legsum<real>(fs[j], isleg);
+    for (int j = 0; j < 6; j++) fb[j] = LDG(sc, 25 + j) + legsum<real>(fs[j], isleg);
     cbias[0] = fb[3]; cbias[1] = fb[4]; cbias[2] = fb[5];
 #pragma unroll
     for (int j = 0; j < 3; j++) cbias[3 + j] = Rb[j] * fb[0] + Rb[3 + j] * fb[1] + Rb[6 + j] * fb[2];

@@ -131,6 +131,12 @@ template <class real> struct Tables {
     std::copy(legc.begin(), legc.end(), M.legc); std::copy(basec.begin(), basec.end(), M.basec); std::copy(colc.begin(), colc.end(), M.colc);
     std::copy(footc.begin(), footc.end(), M.footc); std::copy(qpos0.begin(), qpos0.end(), M.qpos0);
     M.maxnbr = NM_HULL_MAXNBR;
+    for (int k = 0; k < 3; k++) {
+      bool id = true;
+      for (int l = 0; l < nm::kNLEG; l++)
+        for (int j = 0; j < 9; j++) id = id && legc[l * nm::kLegN + k * nm::kLinkN + 3 + j] == real(j % 4 == 0 ? 1 : 0);
+      M.link_rot_id[k] = id ? 1 : 0;
+    }
     M.total_mass = (real)total_mass;
     M.h = (real)NM_TIMESTEP; M.kv = (real)NM_KV; M.ctrl_max = (real)NM_CTRL_MAX; M.grav = (real)(-nm_gravity[2]); M.mu = (real)NM_FRICTION;
     double dmax = nm_solimp[1], tc = nm_solref[0], dr = nm_solref[1];
