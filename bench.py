@@ -131,10 +131,11 @@ def main():
     ncoll = 0
     mism = torch.zeros((), dtype=torch.int64, device=dev)      # gathered[rank*E:(rank+1)*E] != what this rank contributed (device-side count)
 
+    env.accumulate_rewards_into(returns)     # returns[env] += reward inside the step kernel (nm_set_return_accumulator), not a launch of its own
+
     def one_step(i, last=False):
         nonlocal returns, gathered, ncoll, mism
-        _, _, rew, done, _ = env.step(acts[i % pool])
-        returns += rew
+        env.step(acts[i % pool])
         # PPO-update boundary: one all-gather of per-env returns over xGMI, every `horizon` steps and at the end of the run (so a
         # short timed region still contains the collective)
         if ((i + 1) % horizon == 0 or last) and world > 1:
@@ -146,6 +147,12 @@ def main():
     def sync():
         if world > 1:
             dist.barrier()
+        # spin on an event first: the blocking wait behind torch.cuda.synchronize() wakes up tens of microseconds after the last
+        # kernel has ended, which a 20-step timed region (1.2 ms) would carry as 3 us per step
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        while not ev.query():
+            pass
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
@@ -157,6 +164,7 @@ def main():
         one_step(args.warmup + i, last=i == args.steps - 1)
     sync()
     dt = time.perf_counter() - t0
+    env.accumulate_rewards_into(None)
     tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -168,11 +176,25 @@ def main():
     if rank == 0:
         value = world * E * args.steps / dt
         # roofline leg: HIP events around the dominant (step) kernel on its launch stream, separate pass
+        # (a) ONE event pair on the launch stream around n back-to-back launches: span / n is the average launch duration including the
+        #     ~1 us between two launches, i.e. an upper bound of what rocprofv3 --kernel-trace reports per launch - the roofline uses it;
+        # (b) the library's own event pair around every launch (nm_profile): each pair costs the queue ~2 us, reported for reference.
+        n_leg = max(300, min(args.steps, 1000))               # >= 300 launches whatever --steps is
+        stream = torch.cuda.current_stream(dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for i in range(20):
+            env.step(acts[i % pool])
+        e0.record(stream)
+        for i in range(n_leg):
+            env.step(acts[i % pool])
+        e1.record(stream)
+        e1.synchronize()
+        k_avg = e0.elapsed_time(e1) / n_leg * 1e-3
         env.profile(True)
-        for i in range(max(300, min(args.steps, 1000))):     # >= 300 back-to-back launches whatever --steps is: on a near-idle queue
-            env.step(acts[i % pool])                          # the event pair itself inflates a 75 us kernel by several us
+        for i in range(n_leg):
+            env.step(acts[i % pool])
         k_ms, k_n = env.profile(False)
-        k_avg = k_ms / max(k_n, 1) * 1e-3
+        k_avg_pairs = k_ms / max(k_n, 1) * 1e-3
         achieved = B_FULL * E / k_avg / 1e9
         # HBM-side bytes per launch and VALU issue utilisation are NOT measured by this process: they come from the committed
         # rocprofv3 --pmc passes of this same command (separate runs, as the counter guide prescribes); null when there are none
@@ -244,7 +266,8 @@ def main():
             "collectives_timed": ncoll, "gather_order_mismatches": int(mism.item()),
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_file and f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)",
-                         "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6,
+                         "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6, "kernel_launches_timed": n_leg,
+                         "kernel_avg_us_event_pair_per_launch": k_avg_pairs * 1e6,
                          "algorithmic_bytes_per_env_step": B_FULL,
                          "valu": valu,
                          "note": "latency/VALU-issue bound, not HBM bound: see DESIGN.md"},

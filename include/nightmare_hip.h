@@ -105,6 +105,12 @@ int nm_set_command_uniforms(nm_env* env, const double* u_host);
 int nm_get_counters(nm_env* env, int64_t* out3);
 /* optional debug dump [N,256] reals (dtype of the env) written by nm_step; NULL disables */
 int nm_set_debug_buffer(nm_env* env, void* dbg_dev);
+/* Running return kept by the step kernel itself: with a DEVICE float [N] buffer set, every nm_step adds the step's reward
+ * (envs/nightmare_v3_env.py:277-288, what step() returns as reward_buffer) to acc[env] - the caller's
+ * `cur_reward_sum += rewards` (rsl_rl OnPolicyRunner.learn, the loop train.py:54 drives) without a second launch per step.
+ * The caller owns, zeroes and reads the buffer (stream-ordered with nm_step); NULL switches it off (the default). Not touched
+ * by nm_step_physics. */
+int nm_set_return_accumulator(nm_env* env, float* acc_dev);
 
 /* Observation noise (envs/nightmare_v3_env.py:109-119 builds noise_scale_vec, :304-305 applies it): with a HOST [66] vector
  * set, every nm_step adds (2u-1)*noise_scale_vec[k] to observation k before the clip, u ~ U[0,1) from the counter RNG

@@ -104,6 +104,7 @@ template <class real> struct Args {
   const real* cmd_u;     // [N,4] or null
   // outputs
   float *obs, *rew, *timeout_now;
+  float* ret_acc;        // optional [N]: ret_acc[env] += reward of this step (the caller's running return), null = off
   int64_t* done;
   real* stat_sum;        // [kNREW] sums of episode sums over envs that reset this step
   int* stat_cnt;         // [4]: #resets this step, #contacts dropped (contact cap), #bad-state resets (mj_check*), #hull-search fallbacks
@@ -2944,6 +2945,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     gst1(A.eplen, env, eplen);
     gst1(A.rngctr, env, ctr);
     gst1(A.rew, env, (float)rew);
+    if (A.ret_acc) gadd1(A.ret_acc, env, (float)rew);
     gst1(A.done, env, (int64_t)(reset ? 1 : 0));
     gst1(A.timeout_now, env, time_out ? 1.0f : 0.0f);
   }
@@ -3318,6 +3320,7 @@ template <class real, class Pub> NM_FN void env_finish2(ShW<real, 2>& w, const M
     if (lives[hh]) {
       const int e = wave * 2 + hh, l0 = 32 * hh;
       A.eplen[e] = ep[hh]; A.rngctr[e] = ctr[hh]; A.rew[e] = (float)rew.v[l0];
+      if (A.ret_acc) A.ret_acc[e] += (float)rew.v[l0];
       A.done[e] = (int64_t)(reset.v[l0] ? 1 : 0); A.timeout_now[e] = time_out.v[l0] ? 1.0f : 0.0f;
     }
 #else
@@ -3325,6 +3328,7 @@ template <class real, class Pub> NM_FN void env_finish2(ShW<real, 2>& w, const M
     gst1(A.eplen, (size_t)env, h1 ? ep[1] : ep[0]);
     gst1(A.rngctr, (size_t)env, h1 ? ctr[1] : ctr[0]);
     gst1(A.rew, (size_t)env, (float)rew);
+    if (A.ret_acc) gadd1(A.ret_acc, (size_t)env, (float)rew);
     gst1(A.done, (size_t)env, (int64_t)(reset ? 1 : 0));
     gst1(A.timeout_now, (size_t)env, time_out ? 1.0f : 0.0f);
   }

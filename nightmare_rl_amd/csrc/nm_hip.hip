@@ -221,6 +221,7 @@ struct nm_env {
   virtual int set_feet(const double* air, const unsigned char* last, const unsigned char* filt) = 0;
   virtual int counters(int64_t* out) = 0;
   virtual void set_dbg(void* p) = 0;
+  virtual void set_ret_acc(float* p) = 0;
   virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
   virtual void set_ablate(int m) = 0;
   virtual int set_noise(const double* vec) = 0;
@@ -491,6 +492,7 @@ template <class real> struct Env : nm_env {
     return 0;
   }
   void set_dbg(void* p) override { A.dbg = (real*)p; }
+  void set_ret_acc(float* p) override { A.ret_acc = p; }
   void set_ablate(int m) override { A.ablate = m; }
   int profiling(int on, double* sum_ms, int64_t* count) override {
     HIPCHK(hipSetDevice(device));
@@ -594,6 +596,7 @@ int nm_set_feet_state(nm_env* env, const double* air, const unsigned char* last,
 int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return env->set_cmd_u(u); }
 int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
+int nm_set_return_accumulator(nm_env* env, float* acc) { NEED(env); env->set_ret_acc(acc); return 0; }
 #ifdef NM_MEASURE   // include/nightmare_hip_measure.h: not part of the shipped ABI
 int nm_set_ablation(nm_env* env, int32_t mask) { NEED(env); env->set_ablate(mask); return 0; }
 #endif

@@ -194,6 +194,9 @@ template <class T> NM_FN T gldv(const T* p, int i) { return ((const NM_GLOBAL(T)
 template <class T> NM_FN void gstv(T* p, int i, T v, bool m) { if (m) ((NM_GLOBAL(T)*)p)[i] = v; }
 template <class T> NM_FN T gld1(const T* p, size_t i) { return ((const NM_GLOBAL(T)*)p)[i]; }   // wave-uniform or single-lane
 template <class T> NM_FN void gst1(T* p, size_t i, T v) { ((NM_GLOBAL(T)*)p)[i] = v; }
+// p[i] += v by the hardware's non-returning float atomic (global_atomic_add_f32): nothing to wait for. The caller is the only writer
+// of that word during the launch, so the sum is the same as a load / add / store.
+NM_FN void gadd1(float* p, size_t i, float v) { __builtin_amdgcn_global_atomic_fadd_f32((NM_GLOBAL(float)*)p + i, v); }
 NM_FN void gld3(const float* p, int i, float* o) { const nm_f4 t = *(const NM_GLOBAL(nm_f4)*)((const NM_GLOBAL(float)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 NM_FN void gld3(const double* p, int i, double* o) { const nm_d4 t = *(const NM_GLOBAL(nm_d4)*)((const NM_GLOBAL(double)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; }
 NM_FN void gld4(const float* p, int i, float* o) { const nm_f4 t = *(const NM_GLOBAL(nm_f4)*)((const NM_GLOBAL(float)*)p + i); o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w; }
@@ -326,6 +329,7 @@ template <class T, class S> NM_FN void stsu(T* a, const V<int>& i, const V<T>& v
 template <class T, class S> NM_FN void stsu(T* a, const V<int>& i, T v, const VB& m, S*) { stsv(a, i, v, m); }
 template <class T> NM_FN T gld1(const T* p, size_t i) { return p[i]; }
 template <class T> NM_FN void gst1(T* p, size_t i, T v) { p[i] = v; }
+NM_FN void gadd1(float* p, size_t i, float v) { p[i] += v; }
 template <class T> NM_FN V<T> gldv(const T* p, const V<int>& i) { return ldsv(p, i); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, const V<T>& v, const VB& m) { stsv(p, i, v, m); }
 template <class T> NM_FN void gstv(T* p, const V<int>& i, T v, const VB& m) { stsv(p, i, v, m); }

@@ -294,6 +294,14 @@ class NightmareV3Env:
         self._dbg = t
         self._ck(self._L.nm_set_debug_buffer(self._h, None if t is None else t.data_ptr()))
 
+    def accumulate_rewards_into(self, t):
+        """t: float32 [num_envs] device tensor (or None = off). Every step() then adds its rewards to t inside the step kernel - the
+        running return a runner keeps (`cur_reward_sum += rewards`) without a launch of its own. The caller zeroes / reads t."""
+        if t is not None and (t.dtype != torch.float32 or t.numel() != self.num_envs or not t.is_contiguous() or t.device != self.obs_buf.device):
+            raise ValueError("accumulate_rewards_into: contiguous float32 [num_envs] tensor on the env's device")
+        self._ret_acc = t
+        self._ck(self._L.nm_set_return_accumulator(self._h, None if t is None else t.data_ptr()))
+
     def profile(self, enable):
         """(sum_ms, count) of step-kernel HIP-event times since the last call; sets event recording on/off."""
         ms, cnt = C.c_double(0), C.c_int64(0)
