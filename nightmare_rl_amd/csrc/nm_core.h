@@ -971,6 +971,43 @@ template <class real_, class st> NM_COLD bool mpr_penetration(const Sh<st>& sh, 
 
 // tibia-tibia pairs: lanes 0..14 run the cull (MuJoCo's bounding-sphere filter AND a conservative separating-axis test of
 // the two hull OBBs along the line of centres); surviving pairs go through MPR one at a time.
+// the pairs the cull let through (bit p of m = pair p), one at a time through MPR
+template <class real> NM_FN void pairs_narrow(Sh<real>& sh, const Model<real>& M, int* dropped, uint64_t m) {
+  if (!m) return;
+  int ncon = sh.ncon;
+  while (m) {
+    int pidx = __builtin_ctzll(m);
+    m &= m - 1;
+    int a = (pidx >= 5) + (pidx >= 9) + (pidx >= 12) + (pidx >= 14);
+    int s0 = a == 0 ? 0 : (a == 1 ? 5 : (a == 2 ? 9 : (a == 3 ? 12 : 14)));
+    int h1 = a + 1, h2 = h1 + 1 + (pidx - s0);
+    {  // mj_filterSphere on the COM-centred bounding spheres
+      const real *R1 = sh.colR + 9 * h1, *R2 = sh.colR + 9 * h2, *k1 = M.colc + kColN * h1, *k2 = M.colc + kColN * h2;
+      real t1[3], t2[3], dd[3];
+      matvec3(t1, R1, k1); matvec3(t2, R2, k2);
+#pragma unroll
+      for (int k = 0; k < 3; k++) dd[k] = (sh.colp[3 * h1 + k] + t1[k]) - (sh.colp[3 * h2 + k] + t2[k]);
+      real bound = k1[3] + k2[3];
+      if (dot3<real>(dd, dd) > bound * bound) continue;
+    }
+    typedef double acc;      // MPR computes in fp64 in both builds (see hull_support)
+    acc depth, dir[3], pos[3];
+    if (!mpr_penetration<acc>(sh, M, h1, h2, &depth, dir, pos)) continue;
+    if (!(depth > acc(0))) continue;
+    if (ncon >= kMaxConBig) { *dropped += 1; continue; }   // cannot happen: see kMaxConBig
+    sh.cpos()[3 * ncon] = (real)pos[0]; sh.cpos()[3 * ncon + 1] = (real)pos[1]; sh.cpos()[3 * ncon + 2] = (real)pos[2];
+    sh.cnrm()[3 * ncon] = (real)dir[0]; sh.cnrm()[3 * ncon + 1] = (real)dir[1]; sh.cnrm()[3 * ncon + 2] = (real)dir[2];
+    sh.cdist()[ncon] = (real)(-depth);
+    sh.cleg()[ncon] = h2 - 1;
+    sh.cleg1()[ncon] = h1 - 1;
+    sh.anypair = 1;
+    ncon++;
+  }
+  sh.ncon = ncon;
+  wave_sync();
+}
+
+
 template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<real>& M, int* dropped) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
@@ -1014,37 +1051,57 @@ template <class real> NM_FN void stage_collide_pairs(Sh<real>& sh, const Model<r
   }
   // MuJoCo's sphere filter is on the mesh COMs; it is implied by the (tighter) OBB test in practice, but keep both exact-conservative
   uint64_t m = ballot(isp & !(dist > e[0] + e[1]));
-  int ncon = sh.ncon;
-  while (m) {
-    int pidx = __builtin_ctzll(m);
-    m &= m - 1;
-    int a = (pidx >= 5) + (pidx >= 9) + (pidx >= 12) + (pidx >= 14);
-    int s0 = a == 0 ? 0 : (a == 1 ? 5 : (a == 2 ? 9 : (a == 3 ? 12 : 14)));
-    int h1 = a + 1, h2 = h1 + 1 + (pidx - s0);
-    {  // mj_filterSphere on the COM-centred bounding spheres
-      const real *R1 = sh.colR + 9 * h1, *R2 = sh.colR + 9 * h2, *k1 = M.colc + kColN * h1, *k2 = M.colc + kColN * h2;
-      real t1[3], t2[3], dd[3];
-      matvec3(t1, R1, k1); matvec3(t2, R2, k2);
+  pairs_narrow(sh, M, dropped, m);
+}
+
+// the same cull for BOTH envs of a wave at once (lanes 0..14 env 0, lanes 32..46 env 1: same arithmetic per lane)
+template <class real> NM_FN void stage_collide_pairs2(ShW<real, 2>& w, const Model<real>& M, int* dropped) {
+  typedef V<real> vr;
+  const V<int> lane = lane_id();
+  const V<int> hl = lane & 31, ho = (lane >> 5) * (int)(sizeof(Sh<real>) / sizeof(real));
+  const real* rb = reinterpret_cast<const real*>(&w.e[0]);
+  const VB isp = hl < 15;
+  const V<int> pl = sel(isp, hl, V<int>(0));
+  V<int> i1 = sel(pl >= 5, V<int>(1), V<int>(0)) + sel(pl >= 9, V<int>(1), V<int>(0)) + sel(pl >= 12, V<int>(1), V<int>(0)) +
+              sel(pl >= 14, V<int>(1), V<int>(0));                       // 0..4
+  V<int> st = sel(i1 == 0, V<int>(0), sel(i1 == 1, V<int>(5), sel(i1 == 2, V<int>(9), sel(i1 == 3, V<int>(12), V<int>(14)))));
+  V<int> g1 = i1 + 1, g2 = g1 + 1 + (pl - st);
+  vr c1[3], c2[3], e[2];
+  V<int> gg[2] = {g1, g2};
+  vr u[3];
 #pragma unroll
-      for (int k = 0; k < 3; k++) dd[k] = (sh.colp[3 * h1 + k] + t1[k]) - (sh.colp[3 * h2 + k] + t2[k]);
-      real bound = k1[3] + k2[3];
-      if (dot3<real>(dd, dd) > bound * bound) continue;
-    }
-    typedef double acc;      // MPR computes in fp64 in both builds (see hull_support)
-    acc depth, dir[3], pos[3];
-    if (!mpr_penetration<acc>(sh, M, h1, h2, &depth, dir, pos)) continue;
-    if (!(depth > acc(0))) continue;
-    if (ncon >= kMaxConBig) { *dropped += 1; continue; }   // cannot happen: see kMaxConBig
-    sh.cpos()[3 * ncon] = (real)pos[0]; sh.cpos()[3 * ncon + 1] = (real)pos[1]; sh.cpos()[3 * ncon + 2] = (real)pos[2];
-    sh.cnrm()[3 * ncon] = (real)dir[0]; sh.cnrm()[3 * ncon + 1] = (real)dir[1]; sh.cnrm()[3 * ncon + 2] = (real)dir[2];
-    sh.cdist()[ncon] = (real)(-depth);
-    sh.cleg()[ncon] = h2 - 1;
-    sh.cleg1()[ncon] = h1 - 1;
-    sh.anypair = 1;
-    ncon++;
+  for (int w = 0; w < 2; w++) {
+    vr R[9], oc[3], c[3];
+#pragma unroll
+    for (int j = 0; j < 9; j++) R[j] = ldsv(rb, ho + (gg[w] * 9 + (j + NM_OFS(colR))));
+#pragma unroll
+    for (int j = 0; j < 3; j++) oc[j] = ldsv(M.colc, gg[w] * kColN + (8 + j));
+    matvec3(c, R, oc);
+#pragma unroll
+    for (int j = 0; j < 3; j++) { c[j] = c[j] + ldsv(rb, ho + (gg[w] * 3 + (j + NM_OFS(colp)))); if (w == 0) c1[j] = c[j]; else c2[j] = c[j]; }
   }
-  sh.ncon = ncon;
-  wave_sync();
+  u[0] = c2[0] - c1[0]; u[1] = c2[1] - c1[1]; u[2] = c2[2] - c1[2];
+  vr dist = vsqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  vr inv = vr(real(1)) / vmax(dist, vr(real(1e-12)));
+  u[0] = u[0] * inv; u[1] = u[1] * inv; u[2] = u[2] * inv;
+#pragma unroll
+  for (int w = 0; w < 2; w++) {  // extent of each OBB along u: sum_i h_i |u . (R a_i)|
+    vr R[9], ul[3];
+#pragma unroll
+    for (int j = 0; j < 9; j++) R[j] = ldsv(rb, ho + (gg[w] * 9 + (j + NM_OFS(colR))));
+    ul[0] = R[0] * u[0] + R[3] * u[1] + R[6] * u[2]; ul[1] = R[1] * u[0] + R[4] * u[1] + R[7] * u[2]; ul[2] = R[2] * u[0] + R[5] * u[1] + R[8] * u[2];
+    vr ext = vr(real(0));
+#pragma unroll
+    for (int a = 0; a < 3; a++) {
+      vr ax[3] = {ldsv(M.colc, gg[w] * kColN + (11 + 3 * a)), ldsv(M.colc, gg[w] * kColN + (12 + 3 * a)), ldsv(M.colc, gg[w] * kColN + (13 + 3 * a))};
+      ext += ldsv(M.colc, gg[w] * kColN + (20 + a)) * vabs(ax[0] * ul[0] + ax[1] * ul[1] + ax[2] * ul[2]);
+    }
+    e[w] = ext;
+  }
+  // MuJoCo's sphere filter is on the mesh COMs; it is implied by the (tighter) OBB test in practice, but keep both exact-conservative
+  uint64_t m = ballot(isp & !(dist > e[0] + e[1]));
+  pairs_narrow(w.e[0], M, dropped, m & 0xffffffffull);
+  pairs_narrow(w.e[1], M, dropped, m >> 32);
 }
 
 // =========================================================================================  stage B
@@ -2571,9 +2628,13 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
   // (stage_constraint2), else one after the other
   for (int e = 0; e < G; e++) {
     Sh<real>& sh = w.e[e];
-    if (!(ablate & 1)) stage_collide(sh, M, dropped, !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
-    if (ablate & 4) { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
+    if (!(ablate & 1)) stage_collide(sh, M, dropped, G != 2 && !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
   }
+  if constexpr (G == 2) {
+    if (!(ablate & 1) && !(ablate & 16)) stage_collide_pairs2(w, M, dropped);   // tibia pairs: the cull of both envs in one pass
+  }
+  for (int e = 0; e < G; e++)
+    if (ablate & 4) { w.e[e].ncon = 0; w.e[e].anypair = 0; wave_sync(); }
   bool together = false;
   if constexpr (G == 2) {
     const int n0 = uniform(w.e[0].ncon), n1 = uniform(w.e[1].ncon);
