@@ -4,7 +4,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/pmcmask
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-for M in 0 1 4 9 13 32; do
+for M in 0 1 4 13; do
   rocprofv3 --kernel-trace --output-format csv --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAVES -d "$OUT/m$M" -o run -- python3 "$ROOT/scripts/pmcmask.py" $M > "$OUT/m$M.log" 2>&1 || echo "mask $M failed"
   echo "mask $M done"
 done
@@ -12,7 +12,7 @@ python3 - "$OUT" <<'P' | tee "$OUT/summary.txt"
 import sys, glob, csv, collections
 out = sys.argv[1]
 names = {0: "full", 1: "no collision (=> no contacts, no constraints)", 4: "no constraint stage", 9: "no collision, no smooth stage", 13: "load + integrate + epilogue only", 32: "constraint stage one env at a time"}
-for m in (0, 1, 4, 9, 13, 32):
+for m in (0, 1, 4, 13):
     f = glob.glob(f"{out}/m{m}/**/*counter_collection.csv", recursive=True)
     if not f: print(m, "no csv"); continue
     rows = [r for r in csv.DictReader(open(f[0])) if "k_env_step" in r["Kernel_Name"]]
