@@ -442,6 +442,24 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
   // arithmetic for the BASE body (pose Rb at the origin, velocity vb, bias acceleration ab, constants from M.basec).
   const V<int> mylink = (grp >> (G == 1 ? 0 : (G == 2 ? 1 : 2))) & 3;      // role: link 0, 1, 2 of the lane's leg, or 3 = the base body
   const VB isbase = mylink == 3;
+#ifndef NM_NO_ROLE_ROT
+  {  // the joint rotations (sine / cosine, Rodrigues about the local axis) do not depend on the parent: each role does its own link's
+     // (the base role link 2's again) and leaves it in the leg staging area for the walk below
+    const V<int> lk = vmin(mylink, V<int>(2));
+    const V<int> cbr = leg * kLegN + lk * kLinkN;
+    const vr ax[3] = {ldsv(M.legc, cbr + 12), ldsv(M.legc, cbr + 13), ldsv(M.legc, cbr + 14)};
+    vr s_, co;
+    vsincos(LDL(qpos, leg * 3 + lk + 7), &s_, &co);
+    const vr oc = vr(real(1)) - co;
+    vr Rl[9];
+    Rl[0] = co + oc * ax[0] * ax[0]; Rl[1] = oc * ax[0] * ax[1] - s_ * ax[2]; Rl[2] = oc * ax[0] * ax[2] + s_ * ax[1];
+    Rl[3] = oc * ax[0] * ax[1] + s_ * ax[2]; Rl[4] = co + oc * ax[1] * ax[1]; Rl[5] = oc * ax[1] * ax[2] - s_ * ax[0];
+    Rl[6] = oc * ax[0] * ax[2] - s_ * ax[1]; Rl[7] = oc * ax[1] * ax[2] + s_ * ax[0]; Rl[8] = co + oc * ax[2] * ax[2];
+#pragma unroll
+    for (int j = 0; j < 9; j++) STL(legtmp, leg * 27 + lk * 9 + j, Rl[j]);
+    wave_sync();
+  }
+#endif
   vr mcom[3] = {vr(real(0)), vr(real(0)), vr(real(0))};
   {
     vr Rp[9], pp[3], vpar[6], apar[6];
@@ -477,13 +495,19 @@ template <class real, int G> NM_FN void stage_smooth(ShW<real, G>& w, const Mode
           }
         }
         matvec3(aw, R0, ax);
+        vr Rl[9];  // Rodrigues about the local axis
+#ifndef NM_NO_ROLE_ROT
+#pragma unroll
+        for (int j = 0; j < 9; j++) Rl[j] = LDL(legtmp, leg * 27 + (k * 9 + j));
+        (void)q;
+#else
         vr s, co;
         vsincos(q, &s, &co);
         vr oc = vr(real(1)) - co;
-        vr Rl[9];  // Rodrigues about the local axis
         Rl[0] = co + oc * ax[0] * ax[0]; Rl[1] = oc * ax[0] * ax[1] - s * ax[2]; Rl[2] = oc * ax[0] * ax[2] + s * ax[1];
         Rl[3] = oc * ax[0] * ax[1] + s * ax[2]; Rl[4] = co + oc * ax[1] * ax[1]; Rl[5] = oc * ax[1] * ax[2] - s * ax[0];
         Rl[6] = oc * ax[0] * ax[2] - s * ax[1]; Rl[7] = oc * ax[1] * ax[2] + s * ax[0]; Rl[8] = co + oc * ax[2] * ax[2];
+#endif
         matmul3(R, R0, Rl);
       }
       // publish joint anchor/axis (row stage) and, for the tibia, the collision frame
@@ -2438,7 +2462,8 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
   real* lds = reinterpret_cast<real*>(&w.e[0]);
   // lane groups as in stage A: group g works on env g % G; groups [0, G) solve with the factor of M (qacc, for the warm start and
   // mj_checkAcc), groups [G, 2G) with the factor of M + h kv I (the implicitfast velocity update) - one pass on different lanes. What
-  // a group's solve does not feed is stored to a junk row of the leg staging area (free here: the contact list is spent).
+  // a group's solve does not feed is stored to a junk row (stage A's mbb / sc, the matrix-free solver's vv: all spent here; the contact
+  // list in the leg staging area stays intact for the debug dump).
   const V<int> lane0 = opaque_lane();
   const V<int> sub = lane0 & 7, grp = lane0 >> 3;
   const V<int> leg = vmin(sub, V<int>(5)), eo = (grp & (G - 1)) * (int)(sizeof(Sh<real>) / sizeof(real));
@@ -2448,7 +2473,7 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
 #define LDL(field, idx) ldsv(lds, eo + (idx) + NM_OFS(field))
   constexpr int kFacH = NM_OFS(MinvH) - NM_OFS(Minv);
   static_assert(NM_OFS(WH) - NM_OFS(W) == kFacH && NM_OFS(LbH) - NM_OFS(Lb) == kFacH && NM_OFS(DbiH) - NM_OFS(Dbi) == kFacH, "factor blocks");
-  static_assert(kNLEG * 66 >= 24 + 28 + 24, "leg staging area holds the junk rows");
+  static_assert(sizeof(Sh<real>::mbb) / sizeof(real) >= 24 && sizeof(Sh<real>::sc) / sizeof(real) >= 28 && sizeof(Sh<real>::vv) / sizeof(real) >= 24, "junk rows");
   const V<int> eoF = eo + sel(pass1, V<int>(kFacH), V<int>(0));
   vr xl[3], xb[6];     // groups [0, G): M^-1 qfrc_constraint ; groups [G, 2G): (M + h kv I)^-1 (qfrc_smooth + qfrc_constraint)
   {
@@ -2525,9 +2550,9 @@ template <class real, int G> NM_FN void stage_integrate(ShW<real, G>& w, const M
     jq[k] = LDL(qpos, leg * 3 + (7 + k)) + M.h * jv[k];
   }
   wave_sync();
-  const V<int> eoV = eo + sel(pass1, V<int>(NM_OFS(qvel)), V<int>(NM_OFS(legtmp)));
-  const V<int> eoP = eo + sel(pass1, V<int>(NM_OFS(qpos)), V<int>(NM_OFS(legtmp) + 24));
-  const V<int> eoW = eo + sel(pass1, V<int>(NM_OFS(legtmp) + 52), V<int>(NM_OFS(warm)));
+  const V<int> eoV = eo + sel(pass1, V<int>(NM_OFS(qvel)), V<int>(NM_OFS(mbb)));
+  const V<int> eoP = eo + sel(pass1, V<int>(NM_OFS(qpos)), V<int>(NM_OFS(sc)));
+  const V<int> eoW = eo + sel(pass1, V<int>(NM_OFS(vv)), V<int>(NM_OFS(warm)));
 #pragma unroll
   for (int j = 0; j < 6; j++) {
     stsv(lds, eoV + j, nv[j], okb);
