@@ -357,26 +357,14 @@ NM_FN void nm_stamp(int) {}
 
 // =========================================================================================  stage A
 // Everything "smooth": kinematics, inertia blocks + both factorisations, bias, servo forces, qacc_smooth - for all G
-// envs of the wave at once. Lanes 8g..8g+5 are the six legs of env g; what is "per env" (base frame, base inertia,
-// Schur complement ...) is computed redundantly by the 8 lanes of the group, so no cross-lane broadcast is needed and
-// sums over legs are three DPP adds (gsum8). The forward pass down each leg chain parks per-link results in the
-// leg's LDS slots; the backward pass picks them up again (keeps the live register set small).
+// envs of the wave at once, on eight lane groups of 8 (lane = leg, 6 of 8 used): group g works on env g % G in role g / G. What is
+// "per env" (base frame, Schur complement ...) is computed redundantly by the 8 lanes of every group of the env, so no cross-lane
+// broadcast is needed and sums over legs are three DPP adds (gsum8). The roles split what would otherwise be repeated instruction
+// sequences on the same lanes: one body's spatial inertia and force each (links 0..2, base), one of the two factorisations each.
+// The forward pass parks per-link results in the leg's LDS slots; the backward pass picks them up again (keeps the live
+// register set small).
 constexpr int kLinkTmp = 22;  // per link in LDS: S(6) I10(10) f(6)
 
-template <class real, int G> struct Grp {  // lane -> (env slot, leg) mapping of the leg-lane stages
-  V<int> sub, leg, eo;
-  VB gact, isleg, lead;
-  NM_FN Grp() {
-    const V<int> lane = opaque_lane();   // recomputed per stage: cheaper than keeping the mapping live (spilled) across stages
-    sub = lane & 7;
-    leg = vmin(sub, V<int>(5));
-    V<int> g = lane >> 3;
-    gact = g < G;
-    isleg = gact & (sub < 6);
-    lead = gact & (sub == 0);
-    eo = vmin(g, V<int>(G - 1)) * (int)(sizeof(Sh<real>) / sizeof(real));
-  }
-};
 template <class real> NM_FN V<real> legsum(const V<real>& x, const VB& isleg) {  // sum over the legs of the lane's env
   return gsum8(sel(isleg, x, V<real>(real(0))));
 }
