@@ -1165,20 +1165,28 @@ template <class real> NM_FN void hull_ring(const Model<real>& M, int gv, int sel
   v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
   nbg = sel(lane == kSelfLane, V<int>(self), sel(nbl, to_int(o[3]), V<int>(-1)));
 }
-template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped, bool pairs = true) {
+// the seven ring gathers of one env (L2 round trips): issued apart from their use, so that a wave can have both of its envs' in flight
+template <class real> struct Rings {
+  V<int> nb[kNCOL];
+  V<real> vv[kNCOL][3];
+  int cur[kNCOL];
+};
+template <class real> NM_FN void collide_rings(const Sh<real>& sh, const Model<real>& M, Rings<real>& r) {
+#pragma unroll
+  for (int g = 0; g < kNCOL; g++) {
+    const int vadr = (int)M.colc[kColN * g + 6];
+    r.cur[g] = uniform(sh.hcache[g]);
+    hull_ring(M, vadr + r.cur[g], r.cur[g], r.nb[g], r.vv[g]);
+  }
+}
+template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped, Rings<real>& rg, bool pairs = true) {
   typedef V<real> vr;
   const V<int> lane = lane_id();
   const real bz = sh.qpos[2];
   const VB nbl = lane < M.maxnbr;
-  V<int> nb[kNCOL];
-  vr vv[kNCOL][3];
-  int cur[kNCOL];
-#pragma unroll
-  for (int g = 0; g < kNCOL; g++) {
-    const int vadr = (int)M.colc[kColN * g + 6];
-    cur[g] = uniform(sh.hcache[g]);
-    hull_ring(M, vadr + cur[g], cur[g], nb[g], vv[g]);
-  }
+  V<int>* nb = rg.nb;
+  vr (*vv)[3] = rg.vv;
+  int* cur = rg.cur;
   // The seven meshes go through the stage together, phase by phase, so that their (independent) dependency chains overlap:
   // P1 frame scalars + bounding-sphere prefilter, P2 support values and the occasional hill climb, P3 contact emission with
   // contact slots from a running count (the order - mesh by mesh, support vertex first, then neighbours in graph order - is
@@ -2641,7 +2649,8 @@ template <class real, int G> NM_FN void substep(ShW<real, G>& w, const Model<rea
   // (stage_constraint2), else one after the other
   for (int e = 0; e < G; e++) {
     Sh<real>& sh = w.e[e];
-    if (!(ablate & 1)) stage_collide(sh, M, dropped, G != 2 && !(ablate & 16)); else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
+    if (!(ablate & 1)) { Rings<real> rg; collide_rings(sh, M, rg); stage_collide(sh, M, dropped, rg, G != 2 && !(ablate & 16)); }
+    else { sh.ncon = 0; sh.anypair = 0; wave_sync(); }
   }
   if constexpr (G == 2) {
     if (!(ablate & 1) && !(ablate & 16)) stage_collide_pairs2(w, M, dropped);   // tibia pairs: the cull of both envs in one pass
