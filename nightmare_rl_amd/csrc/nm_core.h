@@ -1619,6 +1619,14 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     const vr K1 = Ajj + shfl_xor1(Ajj) - Amq - Amq;
     const VB small = K1 < vr(real(1e-15));       // degenerate pair: both forces go to their mean
     const vr invK1 = vrcp(K1), hK1 = real(0.5) * K1;
+    // d_partner = -d exactly (the subtraction, the clamp and the halved difference are antisymmetric in the pair), so a pair moves every
+    // residual by (A[.][2p] - A[.][2p+1]) d(2p): one broadcast and one fma per pair. The sweeps of mj_solPGS are over: the column
+    // difference takes the even column's registers.
+    for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
+      constexpr int cc = decltype(ccT)::value;
+      A[4 * cc] = A[4 * cc] - A[4 * cc + 1];
+      A[4 * cc + 2] = A[4 * cc + 2] - A[4 * cc + 3];
+    });
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       real improvement = real(0);
       if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
@@ -1633,7 +1641,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
           const vr change = d * (hK1 * d + dg);
           const VB bad = change > vr(real(1e-10));     // costChange: revert an update that does not decrease the cost
           d = sel(bad, vr(real(0)), d);
-          g += A[2 * p] * rdlane(d, 2 * p) + A[2 * p + 1] * rdlane(d, 2 * p + 1);
+          g += A[2 * p] * rdlane(d, 2 * p);
           const VB me = lvp == p;
           dcap = sel(me, d, dcap);
           ccap = sel(me & even & !bad, change, ccap);
@@ -1971,6 +1979,11 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
     const vr K1 = Ajj + shfl_xor1(Ajj) - Amq - Amq;
     const VB small = K1 < vr(real(1e-15));
     const vr invK1 = vrcp(K1), hK1 = real(0.5) * K1;
+    for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {     // column differences, as in stage_constraint_body
+      constexpr int cc = decltype(ccT)::value;
+      A[4 * cc] = A[4 * cc] - A[4 * cc + 1];
+      A[4 * cc + 2] = A[4 * cc + 2] - A[4 * cc + 3];
+    });
     VB run = VB(true);
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       vr improvement = vr(real(0));
@@ -1986,7 +1999,7 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
           const vr change = d * (hK1 * d + dg);
           const VB bad = change > vr(real(1e-10));
           d = sel(bad | !run, vr(real(0)), d);
-          g += A[2 * p] * RDL(d, 2 * p) + A[2 * p + 1] * RDL(d, 2 * p + 1);
+          g += A[2 * p] * RDL(d, 2 * p);
           const VB me = lvp == p;
           dcap = sel(me, d, dcap);
           ccap = sel(me & even & !bad & run, change, ccap);
