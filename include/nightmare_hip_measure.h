@@ -11,7 +11,8 @@ extern "C" {
 #endif
 /* Results become wrong (except bit5): skip kernel stages to attribute time. bit0 collision, bit1 solver sweeps, bit2 whole
  * constraint stage, bit3 smooth-dynamics stage, bit4 tibia pairs, bit5 constraint stage one env at a time (same results),
- * bit7 env epilogue, bit8 observation. 0 = normal. Also only in this build: NM_MEASURE_PGS_ITERS / NM_MEASURE_NOSLIP_ITERS
+ * bit7 env epilogue, bit8 observation, bit9 the empty launch (every wave returns at once), bit10 load stage only, bit11 no substeps
+ * (load + epilogue). 0 = normal. Also only in this build: NM_MEASURE_PGS_ITERS / NM_MEASURE_NOSLIP_ITERS
  * (environment, read by nm_create) override the solver sweep counts. */
 int nm_set_ablation(nm_env* env, int32_t mask);
 #ifdef __cplusplus

@@ -120,7 +120,7 @@ template <class real> struct Args {
   int nsub;              // decimation
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
   int ablate;            // read only by -DNM_MEASURE builds (the shipped library has no way to set it and compiles the tests away): bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage, bit4 no tibia pairs,
-                         // bit5 constraint stage one env at a time, bit7 no env epilogue (E3-E8), bit8 no observation
+                         // bit5 constraint stage one env at a time, bit7 no env epilogue (E3-E8), bit8 no observation, bit9 empty launch, bit10 load only, bit11 no substeps
   // observation noise (env.py:109-119,304-305): null = off
   const real* noise_vec; // [66] noise_scale_vec
   const real* noise_u;   // [N,66] injected uniforms (parity tests) or null = counter RNG
@@ -3449,6 +3449,8 @@ NM_FN void wave_step(ShW<real, G>& w, const Model<real>& M, const Args<real>& A,
   }
   nm_stamp(0);
   int dropped = 0;
+  if (NM_ABLATE(A.ablate) & 1024) return;   // measurement only: load stage alone
+  if (!(NM_ABLATE(A.ablate) & 2048))
   for (int s = 0; s < A.nsub; s++) substep(w, M, s == A.nsub - 1, &dropped, NM_ABLATE(A.ablate));
   if constexpr (G == 2) {
     env_finish2(w, M, A, wave, dropped, published);

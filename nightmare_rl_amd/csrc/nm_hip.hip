@@ -92,6 +92,9 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
   }
 #endif
   if (wave * G >= A.N) return;
+#ifdef NM_MEASURE
+  if (A.ablate & 512) return;      // measurement only: the empty launch
+#endif
   const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
   As = A;
   __syncthreads();
