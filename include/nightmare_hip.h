@@ -190,6 +190,14 @@ int32_t nm_ppo_has_fast_path(const nm_ppo* h);
  * update's packed weights (always current: no repack between update and collection), then exactly what nm_ppo_sample does */
 int nm_ppo_act(nm_ppo* h, const float* flat_dev, const float* obs_dev, int32_t N, uint64_t seed, const int64_t* iter_dev, int32_t step,
                float* actions_dev, float* logp_dev, float* values_dev, float* mu_dev, float* sigma_dev, float* obs_store_dev, void* stream);
+/* nm_ppo_record of the PREVIOUS step and nm_ppo_act of this one in one launch (the record part runs first; arguments as in the two
+ * calls, prev_values_dev = the values nm_ppo_act filed for the previous step): PPO.process_env_step(s - 1) + PPO.act(s) of rsl_rl
+ * v1.0.2 (caller reference train.py:54). A rollout of T steps needs T + 1 of these launches besides the env's instead of 2 T. */
+int nm_ppo_record_act(nm_ppo* h, const float* rew_dev, const int64_t* done_dev, const float* time_outs_dev, const float* prev_values_dev, float gamma,
+                      float* rewards_store_dev, unsigned char* dones_store_dev, float* cur_ret_dev, float* cur_len_dev, float* fin3_dev,
+                      const float* ep_stats_dev, const int32_t* ep_idx_dev, int32_t n_ep, float* ep_acc_dev,
+                      const float* flat_dev, const float* obs_dev, int32_t N, uint64_t seed, const int64_t* iter_dev, int32_t step,
+                      float* actions_dev, float* logp_dev, float* values_dev, float* mu_dev, float* sigma_dev, float* obs_store_dev, void* stream);
 /* gradient of the last mini-batch in flat order followed by the mini-batch's mean KL to the behaviour policy, [num_params + 1] floats:
  * direction 0 copies them to grad_dev, 1 replaces them by grad_dev */
 int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream);

@@ -671,10 +671,19 @@ __device__ __forceinline__ float ppo_u24(uint64_t seed, uint64_t a, uint64_t b) 
   x ^= x >> 31;
   return ((float)(uint32_t)(x >> 40) + 1.0f) * (1.0f / 16777216.0f);
 }
+// the bookkeeping of the PREVIOUS step (what nm_ppo_record does), done at the head of the next PPO.act launch: rew == nullptr = nothing to do
+struct PpoRecord {
+  const float* rew; const int64_t* done; const float* time_outs; const float* values;
+  float gamma;
+  float* rewards_store; unsigned char* dones_store;
+  float *cur_ret, *cur_len, *fin3;
+  const float* ep_stats; const int* ep_idx; int n_ep; float* ep_acc;
+};
 template <class S>
 __global__ void __launch_bounds__(64) k_ppo_act_fast(PpoNet net, const float* __restrict__ obs, const float* __restrict__ std, int N, uint64_t seed,
                                                      const int64_t* __restrict__ iter_dev, int step, float* __restrict__ actions, float* __restrict__ logp,
-                                                     float* __restrict__ values, float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ obs_store) {
+                                                     float* __restrict__ values, float* __restrict__ mu, float* __restrict__ sigma, float* __restrict__ obs_store,
+                                                     PpoRecord rec) {
   typedef Seq<S> Q;
   constexpr int NL = S::NL, MT = S::maxT(), PO = S::P(NL) / 16, AO = S::aout(NL - 1), I = S::Kr(0), T0 = S::P(0) / 16, NF = Q::count(true);
   static_assert(AO % 2 == 0, "action pairs");
@@ -682,6 +691,20 @@ __global__ void __launch_bounds__(64) k_ppo_act_fast(PpoNet net, const float* __
   const int row = blockIdx.x * 16 + r;
   const bool live = row < N;
   const size_t lrow = live ? row : 0;
+  if (rec.rew) {     // k_ppo_record for the step before this one (same arithmetic, env = row): the launch it would have been is this one
+    if (blockIdx.x == 0)
+      for (int e = lane; e < rec.n_ep; e += 64) rec.ep_acc[e] += rec.ep_stats[rec.ep_idx[e]];
+    if (q == 0 && live) {
+      const float rw = rec.rew[row];
+      const bool d = rec.done[row] > 0;
+      rec.rewards_store[row] = rw + (rec.time_outs ? rec.gamma * rec.values[row] * rec.time_outs[row] : 0.0f);
+      rec.dones_store[row] = d ? 1 : 0;
+      const float cr = rec.cur_ret[row] + rw, cl = rec.cur_len[row] + 1.0f;
+      if (d) { atomicAdd(rec.fin3, cr); atomicAdd(rec.fin3 + 1, cl); atomicAdd(rec.fin3 + 2, 1.0f); }
+      rec.cur_ret[row] = d ? 0.0f : cr;
+      rec.cur_len[row] = d ? 0.0f : cl;
+    }
+  }
   auto wfrag = [&](auto IDX) -> f32x4 {
     constexpr int e = Q::entry(true, IDX), l = e & 15, to = (e >> 4) & 15, tk = e >> 8;
     return net.pf[l][(to * (S::P(l) / 16) + tk) * 64 + lane];
@@ -1087,8 +1110,26 @@ extern "C" int nm_ppo_act(nm_ppo* h, const float* flat_dev, const float* obs, in
   if (!h->fast) return nm_policy_set_error("nm_ppo_act: this network shape has no compiled fast path (use nm_policy_forward + nm_ppo_sample)");
   PPO_CHK(hipSetDevice(h->device));
   hipLaunchKernelGGL(k_ppo_act_fast<RefShape>, dim3((N + 15) / 16), dim3(64), 0, (hipStream_t)stream, h->net, obs, flat_dev + (h->nparam - h->A), N, seed, iter_dev,
-                     step, actions, logp, values, mu, sigma, obs_store);
+                     step, actions, logp, values, mu, sigma, obs_store, PpoRecord{});
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_act: launch failed");
+  return 0;
+}
+// nm_ppo_record of the previous step and nm_ppo_act of this one in ONE launch (the record part first; same arguments and meaning as the
+// two calls): a rollout of T steps is T + 1 launches besides the env's instead of 2 T
+extern "C" int nm_ppo_record_act(nm_ppo* h, const float* rew, const int64_t* done, const float* time_outs, const float* prev_values, float gamma,
+                                 float* rewards_store, unsigned char* dones_store, float* cur_ret, float* cur_len, float* fin3,
+                                 const float* ep_stats, const int32_t* ep_idx, int32_t n_ep, float* ep_acc,
+                                 const float* flat_dev, const float* obs, int32_t N, uint64_t seed, const int64_t* iter_dev, int32_t step,
+                                 float* actions, float* logp, float* values, float* mu, float* sigma, float* obs_store, void* stream) {
+  if (!h || !flat_dev || !obs || !iter_dev || !actions || !logp || !values || !mu || !sigma || N <= 0) return nm_policy_set_error("nm_ppo_record_act: bad argument");
+  if (!rew || !done || !prev_values || !rewards_store || !dones_store || !cur_ret || !cur_len || !fin3) return nm_policy_set_error("nm_ppo_record_act: bad record argument");
+  if (n_ep < 0 || n_ep > 256 || (n_ep > 0 && (!ep_stats || !ep_idx || !ep_acc))) return nm_policy_set_error("nm_ppo_record_act: bad episode-statistics arguments");
+  if (!h->fast) return nm_policy_set_error("nm_ppo_record_act: this network shape has no compiled fast path");
+  PPO_CHK(hipSetDevice(h->device));
+  PpoRecord rec{rew, done, time_outs, prev_values, gamma, rewards_store, dones_store, cur_ret, cur_len, fin3, ep_stats, ep_idx, n_ep, ep_acc};
+  hipLaunchKernelGGL(k_ppo_act_fast<RefShape>, dim3((N + 15) / 16), dim3(64), 0, (hipStream_t)stream, h->net, obs, flat_dev + (h->nparam - h->A), N, seed, iter_dev,
+                     step, actions, logp, values, mu, sigma, obs_store, rec);
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_record_act: launch failed");
   return 0;
 }
 // gradient of the last mini-batch in flat order followed by its mean KL, nparam + 1 floats: direction 0 copies them into grad_dev,

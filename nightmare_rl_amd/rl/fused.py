@@ -1,8 +1,10 @@
 """Rollout collection on hand-written kernels: what rsl_rl v1.0.2's `PPO.act` + `PPO.process_env_step` do per step (actor mean,
 critic value, Normal sample, log-probability, transition record, time-out bootstrap, episode bookkeeping; caller reference
 train.py:54), writing straight into the rollout storage:
-  * networks of the reference's shape, next to a FusedUpdate: TWO launches per step - `nm_ppo_act` (register-resident forward of the
-    merged actor+critic network from the update's own packed weights + sampling head) and `nm_ppo_record`;
+  * networks of the reference's shape, next to a FusedUpdate: ONE launch per step - `nm_ppo_record_act`: the bookkeeping of the previous
+    step (`nm_ppo_record`'s arithmetic) at the head of `nm_ppo_act` (register-resident forward of the merged actor+critic network from
+    the update's own packed weights + sampling head); the first act of a rollout is a plain `nm_ppo_act`, the last step's bookkeeping
+    one `nm_ppo_record` (`flush`, from PPO.end_rollout);
   * other qualifying networks: THREE - the fused actor+critic forward on the matrix cores (`nm_policy_forward` on one merged network:
     the two MLPs side by side, block-diagonal hidden layers), `nm_ppo_sample`, `nm_ppo_record`; the packed copy of the parameters is
     refreshed once per iteration by `refresh()`, outside any captured graph.
@@ -43,6 +45,8 @@ class FusedCollector:
         self.iter_dev = torch.zeros(1, dtype=torch.int64, device=self.device)
         self.seed = int(seed)
         self._L = _lib.load()
+        self._pending = None          # arguments of a record() that waits for the next act() (defer_record)
+        self.defer_record = False     # set by PPO: record(s) rides at the head of act(s + 1); PPO.end_rollout / compute_returns flush the last one
         self.refresh(0)
 
     @torch.no_grad()
@@ -66,6 +70,13 @@ class FusedCollector:
         obs = obs if (obs.dtype == torch.float32 and obs.is_contiguous()) else obs.contiguous().float()
         if self.update is not None:
             stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            if self._pending is not None:      # the previous step's bookkeeping rides at the head of this launch
+                rec, self._pending = self._pending, None
+                _lib.check(self._L.nm_ppo_record_act(self.update._h, *rec, self.update.flat.data_ptr(), obs.data_ptr(), self.N, self.seed,
+                                                     self.iter_dev.data_ptr(), s, storage.actions[s].data_ptr(), storage.actions_log_prob[s].data_ptr(),
+                                                     storage.values[s].data_ptr(), storage.mu[s].data_ptr(), storage.sigma[s].data_ptr(),
+                                                     storage.observations[s].data_ptr(), stream))
+                return storage.actions[s]
             _lib.check(self._L.nm_ppo_act(self.update._h, self.update.flat.data_ptr(), obs.data_ptr(), self.N, self.seed, self.iter_dev.data_ptr(), s,
                                           storage.actions[s].data_ptr(), storage.actions_log_prob[s].data_ptr(), storage.values[s].data_ptr(),
                                           storage.mu[s].data_ptr(), storage.sigma[s].data_ptr(), storage.observations[s].data_ptr(), stream))
@@ -89,12 +100,29 @@ class FusedCollector:
         if rewards.numel() != self.N or dones.numel() != self.N or (time_outs is not None and time_outs.numel() != self.N):
             raise ValueError(f"record: rewards / dones / time_outs must hold {self.N} entries")
         self._keep = (rewards, dones, time_outs)          # converted copies stay alive until the launch has read them
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         eps, epi, n_ep, epa = (ep[0].data_ptr(), ep[1].data_ptr(), int(ep[1].numel()), ep[2].data_ptr()) if ep is not None else (None, None, 0, None)
+        if self.update is not None and self.defer_record:
+            # one-launch collection: nothing is launched here, the arguments ride at the head of the next act() (nm_ppo_record_act);
+            # flush() files the last step of a rollout. The env's reward / done / time-out buffers stay valid until its next step().
+            self.flush()
+            self._pending = (rewards.data_ptr(), dones.data_ptr(), None if time_outs is None else time_outs.data_ptr(), storage.values[s].data_ptr(),
+                             float(gamma), storage.rewards[s].data_ptr(), storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(),
+                             fin.data_ptr(), eps, epi, n_ep, epa)
+            storage.step += 1
+            return
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._L.nm_ppo_record(rewards.data_ptr(), dones.data_ptr(), None if time_outs is None else time_outs.data_ptr(),
                                          storage.values[s].data_ptr(), float(gamma), self.N, storage.rewards[s].data_ptr(),
                                          storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(), eps, epi, n_ep, epa, stream))
         storage.step += 1
+
+    def flush(self):
+        """Launch the bookkeeping of a step whose act() successor has not come (the last step of a rollout). A no-op otherwise."""
+        if self._pending is None:
+            return
+        rec, self._pending = self._pending, None
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_record(rec[0], rec[1], rec[2], rec[3], rec[4], self.N, *rec[5:], stream))
 
 
 class FusedUpdate:

@@ -44,6 +44,7 @@ class PPO:
                     self.fused_update = None
             rank = dist.get_rank() if _world() > 1 else 0     # every rank draws its own action noise
             self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=(torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF, update=self.fused_update)
+            self.fused.defer_record = True     # one launch per collection step (nm_ppo_record_act); end_rollout() files the last step
 
     def after_load(self):
         """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow. The adaptive-KL schedule resumes
@@ -101,7 +102,14 @@ class PPO:
         self.actor_critic.reset(dones)
         return False
 
+    def end_rollout(self):
+        """After the last process_env_step of a rollout (the runner calls it inside the region it captures into a graph): the fused
+        collector files the bookkeeping of the last step, which has no act() after it to ride on."""
+        if getattr(self, "fused", None) is not None:
+            self.fused.flush()
+
     def compute_returns(self, last_critic_obs):
+        self.end_rollout()
         last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 

@@ -110,6 +110,8 @@ class OnPolicyRunner:
                     if ep_acc is None:
                         ep_acc = torch.zeros_like(e)
                     ep_acc.add_(e)
+            if hasattr(alg, "end_rollout"):
+                alg.end_rollout()
             # The rollout starts from a buffer of its own: a captured graph reads and writes fixed addresses, and an env that
             # alternates its observation buffers ends an odd-length rollout in the buffer the next replay would NOT read first.
             if on_gpu and priv is None:
