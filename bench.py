@@ -196,6 +196,22 @@ def main():
         k_ms, k_n = env.profile(False)
         k_avg_pairs = k_ms / max(k_n, 1) * 1e-3
         achieved = B_FULL * E / k_avg / 1e9
+        # The same region once more (reset, W warm-up steps, K timed steps) right after the >= 600 back-to-back launches above: a short
+        # timed region at the start of a process runs at the clocks of an idle GPU (scripts/warmclock.py: 57.8 us/step cold, 53.4 us/step
+        # after 0.2 s of sustained load); `value` above is the cold one when --steps is small. Reported, not used for `value`.
+        sustained = None
+        if world == 1:
+            env.reset()
+            for i in range(args.warmup):
+                env.step(acts[i % pool])
+            sync()
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                env.step(acts[(args.warmup + i) % pool])
+            sync()
+            dts = time.perf_counter() - t1
+            sustained = {"value": E * args.steps / dts, "ms_per_step": dts / args.steps * 1e3,
+                         "note": "the timed region repeated (reset, warm-up, timed steps) right after >= 600 back-to-back launches: GPU at its sustained clock"}
         # HBM-side bytes per launch and VALU issue utilisation are NOT measured by this process: they come from the committed
         # rocprofv3 --pmc passes of this same command (separate runs, as the counter guide prescribes); null when there are none
         traffic = valu = None
@@ -264,6 +280,7 @@ def main():
                        "envs_per_gpu": E, "decimation": 2,
                        "sharding": f"dp{world} by env id, all-gather of returns every {horizon} steps and on the last timed step"},
             "collectives_timed": ncoll, "gather_order_mismatches": int(mism.item()),
+            "same_region_at_sustained_clock": sustained,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": pmc_file and f"{pmc_file} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; not measured in this run)",
                          "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6, "kernel_launches_timed": n_leg,
