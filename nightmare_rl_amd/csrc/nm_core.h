@@ -1574,7 +1574,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
     // A row's update is decided by its own lane at its own step: the lane keeps (delta, cost change) and applies them to
     // f after the sweep; the other lanes only need the delta, which reaches them through g.
-    vr dcap = vr(real(0)), ccap = vr(real(0));
+    vr dcap = vr(real(0)), rcap = vr(real(0));
     const V<int> lv = opaque_lane();
     for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
       constexpr int cc = decltype(ccT)::value;
@@ -1583,16 +1583,17 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
         const int i = 4 * cc + r;
         vr res = g + Rr * f;
         vr dl = vmax(-res * ARinv, -f);              // = max(f - res/AR_ii, 0) - f
-        // 0.5 dl^2 AR_ii + dl res. mj_solPGS reverts an update whose cost change exceeds +1e-10; for this projected
-        // coordinate step that cannot happen: unclamped, 0.5 AR dl + res = res (1 - 0.5 AR/AR~) has the sign of res = -sign(dl);
-        // clamped at zero, res >= AR f makes it -f (res - 0.5 AR f) <= 0 - no cancellation in either case, so no test.
-        vr change = dl * (hA * dl + res);
         g += A[i] * rdlane(dl, i);
         VB me = lv == i;
         dcap = sel(me, dl, dcap);
-        ccap = sel(me, change, ccap);
+        rcap = sel(me, res, rcap);                   // the residual the row saw at its own step
       }
     });
+    // cost change of a row, 0.5 dl^2 AR_ii + dl res, formed once after the sweep from what the lane kept. mj_solPGS reverts an update
+    // whose cost change exceeds +1e-10; for this projected coordinate step that cannot happen: unclamped, 0.5 AR dl + res =
+    // res (1 - 0.5 AR/AR~) has the sign of res = -sign(dl); clamped at zero, res >= AR f makes it -f (res - 0.5 AR f) <= 0 - no
+    // cancellation in either case, so no test.
+    const vr ccap = dcap * (hA * dcap + rcap);
     f = f + dcap;
     sh.it_pgs = iter + 1;
     if (-wsum<real>(ccap) * M.pgs_scale < M.pgs_tol) break;
@@ -1941,7 +1942,7 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   {
     VB run = VB(true);
     for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
-      vr dcap = vr(real(0)), ccap = vr(real(0));
+      vr dcap = vr(real(0)), rcap = vr(real(0));
       const V<int> lv = opaque_lane() & 31;
       for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
         constexpr int cc = decltype(ccT)::value;
@@ -1950,13 +1951,13 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
           const int i = 4 * cc + r;
           vr res = g + Rr * f;
           vr dl = sel(run, vmax(-res * ARinv, -f), vr(real(0)));
-          vr change = dl * (hA * dl + res);
           g += A[i] * RDL(dl, i);
           VB me = lv == i;
           dcap = sel(me, dl, dcap);
-          ccap = sel(me, change, ccap);
+          rcap = sel(me, res, rcap);       // the residual this row saw at its own step: its cost change is formed once, after the sweep
         }
       });
+      const vr ccap = dcap * (hA * dcap + rcap);
       f = f + dcap;
       itp = itp + sel(run, V<int>(1), V<int>(0));
       run = run & !((-hsum32(ccap)) * M.pgs_scale < vr(M.pgs_tol));
