@@ -4,8 +4,9 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--envs-per-gpu 4096]
 
 One "step" = one step() call over all envs of a rank = `decimation` (2) physics substeps of 8 ms + the env
-epilogue (obs / rewards / termination / reset), random actions already resident in HBM. N>1 is launched by
-torch.distributed.run, one rank per GPU: envs shard contiguously by global id (rank r owns [r*E, (r+1)*E)), the
+epilogue (obs / rewards / termination / reset), random actions already resident in HBM. N>1: one rank per GPU, either started by
+`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` or - when called directly - by bench.py itself, which then
+starts exactly that command as a child process before touching the GPU; envs shard contiguously by global id (rank r owns [r*E, (r+1)*E)), the
 rollout needs no communication, and every 80 steps (num_steps_per_env, reference envs/nightmare_v3_config.py:135)
 the ranks all-gather their per-env returns over RCCL, as a PPO-update boundary would. Rank 0 prints ONE JSON line.
 """
@@ -86,10 +87,15 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     import __graft_entry__ as ge
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` called directly: build once, then start the N ranks as child processes of THIS process (which has
+        # not touched the GPU and does not) and leave with their status; rank 0's JSON line goes to the inherited stdout
+        from nightmare_rl_amd.distributed import self_launch
+        ge.compile_only()
+        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: pass the rank count the launcher started")
     if rank == 0:
         ge.build()
     dist = None

@@ -74,10 +74,16 @@ int nm_reset(nm_env* env, const int32_t* ids_host, int32_t n, int64_t* episode_l
  *   obs_dev [N,66] f32, rew_dev [N] f32, done_dev [N] i64: the returned tuple (:311)
  *   time_outs_dev [N] f32, ep_stats_dev [NM_NUM_REWARDS] f32: extras; like the reference (:344-371) they are only
  *   refreshed by a step in which at least one env reset. A refresh of the buffer the previous refresh wrote is incremental (its
- *   ones are cleared, the new ones set), so the caller must not write into time_outs_dev between steps; any other buffer
- *   (a first call, a new allocation) is rewritten in full - decided on the device, also for launches replayed from a graph. */
+ *   ones are cleared, the new ones set), so the caller must not write into time_outs_dev between steps; a buffer at ANOTHER ADDRESS
+ *   (a first call, a different allocation) is rewritten in full - decided on the device, also for launches replayed from a graph.
+ *   Only the address is compared: a caller that frees the buffer and gets the same address back from its allocator, or overwrites the
+ *   buffer's contents, must call nm_invalidate_time_outs() before the next step. */
 int nm_step(nm_env* env, const float* actions_dev, int64_t* episode_length_dev, float* obs_dev, float* rew_dev,
             int64_t* done_dev, float* time_outs_dev, float* ep_stats_dev, void* stream);
+
+/* Forget which time_outs buffer the last refresh wrote: the next refresh rewrites the whole buffer it is given (stream-ordered).
+ * For callers that re-allocate or overwrite their extras['time_outs'] tensor (envs/nightmare_v3_env.py:369-371 builds a new one each time). */
+int nm_invalidate_time_outs(nm_env* env, void* stream);
 
 /* Physics only: action -> PD velocity command -> mj_step x decimation (envs/nightmare_v3_env.py:152-210),
  * no rewards/obs/reset (BASELINE config "dynamics+contact kernel only"). */
@@ -166,7 +172,7 @@ int nm_ppo_record(const float* rew_dev, const int64_t* done_dev, const float* ti
 
 /* ---- PPO mini-batch update (rsl_rl v1.0.2 `algorithms/ppo.py` PPO.update: clipped surrogate + clipped value loss + entropy bonus,
  * adaptive-KL learning rate, gradient-norm clipping, Adam; caller reference train.py:54; hyper-parameters envs/nightmare_v3_config.py:111-128)
- * as four launches per mini-batch with no host synchronisation. actor_dims / critic_dims = {n_obs, h1, ..., n_out} (same depth, same
+ * as five launches per mini-batch (forward/backward, reduce, scalars, Adam, pack) with no host synchronisation. actor_dims / critic_dims = {n_obs, h1, ..., n_out} (same depth, same
  * observation, critic output 1, ELU). The parameters live in ONE caller-owned flat device vector in the order
  * actor W0 b0 W1 b1 ..., critic W0 b0 ..., std[A] (W row-major [out, in] as torch.nn.Linear); Adam's moments in two more such vectors. */
 typedef struct nm_ppo nm_ppo;

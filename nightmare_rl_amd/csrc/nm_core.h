@@ -19,8 +19,8 @@
 //   stage D  "lane = leg": implicitfast solve, semi-implicit Euler, quaternion integration.
 //   epilogue "lane = observation slot": frame transforms, termination, reset, rewards, obs.
 //
-// All inter-stage traffic goes through ~6.6 KB of LDS per wave; HBM is touched once per env-step
-// (state in, state + obs out).
+// All inter-stage traffic goes through the wave's LDS (18.6 KB per wave of two envs: two env images, the row buffer, the wave's copy
+// of the model constants and of the launch arguments); HBM is touched once per env-step (state in, state + obs out).
 #pragma once
 #include <type_traits>
 #include <stddef.h>
@@ -118,6 +118,7 @@ template <class real> struct Args {
   long long* counters;   // [3] running totals of stat_cnt[1..3]
   real* dbg;             // optional [N][kDbgN]
   int nsub;              // decimation
+  int nxcd;              // XCDs the dispatcher deals workgroups over (hipDeviceAttributeNumberOfXccs); the block -> wave remap is used only when it is 8
   int physics_only;      // 1: skip env epilogue (BASELINE config 2: dynamics+contact only)
   int ablate;            // read only by -DNM_MEASURE builds (the shipped library has no way to set it and compiles the tests away): bit0 no collision, bit1 no solver sweeps, bit2 no constraint stage, bit3 no smooth stage, bit4 no tibia pairs,
                          // bit5 constraint stage one env at a time, bit7 no env epilogue (E3-E8), bit8 no observation, bit9 empty launch, bit10 load only, bit11 no substeps

@@ -19,9 +19,9 @@ static int fail(const std::string& m) { g_err = m; return 1; }
   } while (0)
 
 // ------------------------------------------------------------------------------------------------ kernels
-// One 64-lane wavefront per env, one wave per workgroup: LDS image private to the wave, no inter-wave sync.
+// One 64-lane wavefront per NM_ENVS_PER_WAVE (2) envs, one wave per workgroup: LDS image private to the wave, no inter-wave sync.
 #ifndef NM_WAVES_PER_SIMD
-#define NM_WAVES_PER_SIMD 2  /* measured: 198 us at 2 (no spills) vs 217 us at 4 (616 B/lane scratch), 4096 envs */
+#define NM_WAVES_PER_SIMD 2  /* the step kernel needs ~250 VGPRs (row-per-lane A matrix): 2 waves per SIMD; a 4-wave budget spills */
 #endif
 #ifndef NM_ENVS_PER_WAVE
 #define NM_ENVS_PER_WAVE 2
@@ -88,7 +88,7 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
 #ifndef NM_NO_XCD_MAP
   {
     const int nwx = (int)gridDim.x >> 3;          // waves per XCD (the remainder, if any, keeps the identity mapping)
-    if (wave < (nwx << 3)) wave = (wave & 7) * nwx + (wave >> 3);
+    if (A.nxcd == 8 && wave < (nwx << 3)) wave = (wave & 7) * nwx + (wave >> 3);   // other partition modes (CPX, DPX): identity
   }
 #endif
   if (wave * G >= A.N) return;
@@ -225,6 +225,7 @@ struct nm_env {
   virtual int counters(int64_t* out) = 0;
   virtual void set_dbg(void* p) = 0;
   virtual void set_ret_acc(float* p) = 0;
+  virtual int invalidate_time_outs(hipStream_t s) = 0;
   virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
   virtual void set_ablate(int m) = 0;
   virtual int set_noise(const double* vec) = 0;
@@ -299,6 +300,11 @@ template <class real> struct Env : nm_env {
     if (slab_init((T.hullv.size() + T.hullnv.size()) * sizeof(real) + (size_t)n * 300 * sizeof(real) + (size_t)n * 64 + (1u << 20))) return 1;
     if (upload(&M.hullv, T.hullv) || upload(&M.hullnv, T.hullnv)) return 1;
     A.N = N; A.seed = seed; A.env_offset = off; A.nsub = cfg.decimation;
+    {
+      int nx = 0;     // the dispatcher's round-robin width: 8 on an MI355X in SPX mode; anything else switches the remap off
+      if (hipDeviceGetAttribute(&nx, hipDeviceAttributeNumberOfXccs, dev) != hipSuccess) { (void)hipGetLastError(); nx = 0; }
+      A.nxcd = nx;
+    }
     size_t n_ = (size_t)N;
     if (dalloc(&A.qpos, n_ * 25) || dalloc(&A.qvel, n_ * 24) || dalloc(&A.qwarm, n_ * 24) || dalloc(&A.dofpos, n_ * 18) ||
         dalloc(&A.dofvel, n_ * 18) || dalloc(&A.act, n_ * 18) || dalloc(&A.cmd, n_ * 3) || dalloc(&A.epsum, n_ * nm::kNREW) || dalloc(&A.feetair, n_ * nm::kNLEG) || dalloc(&A.feetflags, n_) ||
@@ -496,6 +502,11 @@ template <class real> struct Env : nm_env {
   }
   void set_dbg(void* p) override { A.dbg = (real*)p; }
   void set_ret_acc(float* p) override { A.ret_acc = p; }
+  int invalidate_time_outs(hipStream_t s) override {
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipMemsetAsync(A.to_owner, 0, sizeof(unsigned long long), s));   // no buffer is "the one the last refresh wrote" any more
+    return 0;
+  }
   void set_ablate(int m) override { A.ablate = m; }
   int profiling(int on, double* sum_ms, int64_t* count) override {
     HIPCHK(hipSetDevice(device));
@@ -600,6 +611,7 @@ int nm_set_command_uniforms(nm_env* env, const double* u) { NEED(env); return en
 int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counters(out2); }
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
 int nm_set_return_accumulator(nm_env* env, float* acc) { NEED(env); env->set_ret_acc(acc); return 0; }
+int nm_invalidate_time_outs(nm_env* env, void* stream) { NEED(env); return env->invalidate_time_outs((hipStream_t)stream); }
 #ifdef NM_MEASURE   // include/nightmare_hip_measure.h: not part of the shipped ABI
 int nm_set_ablation(nm_env* env, int32_t mask) { NEED(env); env->set_ablate(mask); return 0; }
 #endif

@@ -19,7 +19,7 @@ _ENV_SPEC = {
         "model_path": "models/nightmare_v3/mjmodel.xml",  # kept for API parity; the model is compiled into the kernels
         "num_envs": 8192, "num_obs": 66, "num_privileged_obs": 0, "num_actions": 18,
         "episode_length_s": 20, "send_timeouts": True, "body_name": "base_link",
-        # contact modes: 0 ignore, 1 penalise, 2 terminate. Only mode 1 (the upstream default) is on the compiled path.
+        # contact modes: 0 ignore, 1 penalise (the upstream default), 2 terminate - all three are compiled and tested (env.py:248-251,479-485)
         "tibia_contact_mode": 1, "tibia_max_contact_force": 2.0,
         "body_contact_mode": 1, "body_max_contact_force": 2.0,
         "termination_contact_force": 160.0,

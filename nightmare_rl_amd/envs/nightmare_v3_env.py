@@ -113,6 +113,7 @@ class NightmareV3Env:
         self.reset_buf = torch.ones(N, dtype=torch.int64, device=dev)
         self.episode_length_buf = torch.zeros(N, dtype=torch.int64, device=dev)  # assignable, like the reference (:88)
         self.time_out_buf = torch.zeros(N, dtype=torch.float32, device=dev)
+        self._to_bound = self.time_out_buf       # the tensor object the kernel's incremental time-out refresh is bound to
         self._ep_stats = torch.zeros(_lib.NUM_REWARDS, dtype=torch.float32, device=dev)
         self._stat_names = names
         self.extras = {}
@@ -196,6 +197,13 @@ class NightmareV3Env:
         ep = self._eplen()
         self._obs_idx ^= 1
         self.obs_buf = self._obs_pair[self._obs_idx]
+        if self.time_out_buf is not self._to_bound:
+            # the caller replaced extras' time-out tensor: a caching allocator may hand out the old address again, which the kernel's
+            # address check cannot tell from "the buffer I refreshed last" - make the next refresh a full rewrite
+            self._ck(self._L.nm_invalidate_time_outs(self._h, self._stream()))
+            self._to_bound = self.time_out_buf
+            if "time_outs" in self.extras:
+                self.extras["time_outs"] = self.time_out_buf
         self._ck(self._L.nm_step(self._h, a.data_ptr(), ep.data_ptr(), self.obs_buf.data_ptr(), self.rew_buf.data_ptr(),
                                    self.reset_buf.data_ptr(), self.time_out_buf.data_ptr(), self._ep_stats.data_ptr(), self._stream()))
         self._last_actions = a  # keep the input alive until the kernel has read it

@@ -99,12 +99,13 @@ class FusedCollector:
         time_outs = None if time_outs is None else want(time_outs.reshape(-1), torch.float32)
         if rewards.numel() != self.N or dones.numel() != self.N or (time_outs is not None and time_outs.numel() != self.N):
             raise ValueError(f"record: rewards / dones / time_outs must hold {self.N} entries")
+        if self.update is not None and self.defer_record:
+            self.flush()                                  # a still-pending record reads the PREVIOUS converted copies: launch it before they lose their last reference
         self._keep = (rewards, dones, time_outs)          # converted copies stay alive until the launch has read them
         eps, epi, n_ep, epa = (ep[0].data_ptr(), ep[1].data_ptr(), int(ep[1].numel()), ep[2].data_ptr()) if ep is not None else (None, None, 0, None)
         if self.update is not None and self.defer_record:
             # one-launch collection: nothing is launched here, the arguments ride at the head of the next act() (nm_ppo_record_act);
             # flush() files the last step of a rollout. The env's reward / done / time-out buffers stay valid until its next step().
-            self.flush()
             self._pending = (rewards.data_ptr(), dones.data_ptr(), None if time_outs is None else time_outs.data_ptr(), storage.values[s].data_ptr(),
                              float(gamma), storage.rewards[s].data_ptr(), storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(),
                              fin.data_ptr(), eps, epi, n_ep, epa)
@@ -115,6 +116,11 @@ class FusedCollector:
                                          storage.values[s].data_ptr(), float(gamma), self.N, storage.rewards[s].data_ptr(),
                                          storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(), eps, epi, n_ep, epa, stream))
         storage.step += 1
+
+    def drop_pending(self):
+        """Forget a deferred record without launching it: the storage it would write into has been cleared (end of an update, a failed
+        graph capture) - its arguments point at a step that no longer exists."""
+        self._pending = None
 
     def flush(self):
         """Launch the bookkeeping of a step whose act() successor has not come (the last step of a rollout). A no-op otherwise."""

@@ -46,13 +46,20 @@ class PPO:
             self.fused = FusedCollector(self.actor_critic, num_envs, self.device, seed=(torch.initial_seed() + 7919 * rank) & 0xFFFFFFFF, update=self.fused_update)
             self.fused.defer_record = True     # one launch per collection step (nm_ppo_record_act); end_rollout() files the last step
 
+    resume_lr_from_checkpoint = False     # runner cfg flag of the same name (not in rsl_rl): see after_load
+
     def after_load(self):
-        """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow. The adaptive-KL schedule resumes
-        from the learning rate the checkpoint's optimizer carried (param_groups[0]['lr']), not from the configured initial rate."""
+        """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow. Like rsl_rl v1.0.2, `learning_rate`
+        keeps the configured initial value: the first adaptive-KL mini-batch then writes it (x or / 1.5) over the rate the optimizer's
+        param_groups were loaded with. With `resume_lr_from_checkpoint` the schedule continues from the checkpoint's rate instead."""
+        lr = self.learning_rate
         if self.optimizer.param_groups:
-            self.learning_rate = float(self.optimizer.param_groups[0]["lr"])
+            if self.resume_lr_from_checkpoint:
+                lr = self.learning_rate = float(self.optimizer.param_groups[0]["lr"])
+            elif not (self.desired_kl is not None and self.schedule == "adaptive"):
+                lr = float(self.optimizer.param_groups[0]["lr"])     # fixed schedule: upstream never rewrites param_groups, the loaded rate is the rate
         if getattr(self, "fused_update", None) is not None:
-            self.fused_update.sync(self.learning_rate)
+            self.fused_update.sync(lr)
 
     def begin_iteration(self, iteration):
         """Once per learning iteration, before the rollout and outside any captured graph: refresh what the collection kernels read."""
@@ -102,6 +109,13 @@ class PPO:
         self.actor_critic.reset(dones)
         return False
 
+    def reset_collection(self):
+        """Empty the rollout storage AND forget a record the fused collector still holds for the next act(): its arguments point into
+        the storage rows that are being discarded."""
+        self.storage.clear()
+        if getattr(self, "fused", None) is not None:
+            self.fused.drop_pending()
+
     def end_rollout(self):
         """After the last process_env_step of a rollout (the runner calls it inside the region it captures into a graph): the fused
         collector files the bookkeeping of the last step, which has no act() after it to ride on."""
@@ -143,7 +157,7 @@ class PPO:
         for g in self.optimizer.param_groups:
             g["lr"] = self.learning_rate
         n = max(st["minibatches"], 1.0)
-        self.storage.clear()
+        self.reset_collection()
         return st["value_loss_sum"] / n, st["surrogate_loss_sum"] / n
 
     def update(self):

@@ -37,6 +37,8 @@ class OnPolicyRunner:
             for p in ac.parameters():
                 dist.broadcast(p.data, 0)
         self.alg = _CLASSES[self.cfg["algorithm_class_name"]](ac, device=device, **self.alg_cfg)
+        # not in rsl_rl: continue the adaptive-KL schedule from a checkpoint's learning rate instead of the configured one
+        self.alg.resume_lr_from_checkpoint = bool(self.cfg.get("resume_lr_from_checkpoint", False))
         self.num_steps_per_env, self.save_interval = self.cfg["num_steps_per_env"], self.cfg["save_interval"]
         # the reference env announces num_privileged_obs = num_obs (env.py:34) but hands out no privileged observations (:317-319):
         # the critic then sees the actor's observation, and a second copy of it in the storage would only cost bandwidth
@@ -150,7 +152,7 @@ class OnPolicyRunner:
                         alg.storage.step = T
                     except Exception as exc:     # keep training on the eager path
                         want_graph = False
-                        alg.storage.clear()
+                        alg.reset_collection() if hasattr(alg, "reset_collection") else alg.storage.clear()
                         if log:
                             print(f"rollout graph capture failed ({type(exc).__name__}: {exc}); staying on the eager path", flush=True)
                         rollout()

@@ -14,6 +14,48 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def test_rccl_world_size_one_probe():
+    """RCCL itself, on the card: a one-rank `nccl` group runs every collective the N>1 job issues (returns all-gather on device tensors,
+    the gradient | KL all-reduce of the data-parallel mini-batch, advantage statistics, parameter broadcast) - tests/tools/rccl_probe.py."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29529", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NM_DIST_BACKEND"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "rccl_probe.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert "RCCL_PROBE_OK" in r.stdout
+    print(r.stdout.strip().splitlines()[-1])
+
+
+def test_bench_py_called_directly_starts_its_own_ranks():
+    """`python bench.py --gpus 2 --steps 20 --warmup 5` - the shape of the driver's N=1 command, no torch.distributed.run in front:
+    bench.py starts the two ranks as child processes itself (gloo rehearsal: they share the one card) and relays rank 0's line."""
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--envs-per-gpu", "1024"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert out["n_gpus"] == 2 and out["steps"] == 20 and out["collectives_timed"] >= 1 and out["gather_order_mismatches"] == 0
+    # without the rehearsal switch a 2-rank RCCL job on a 1-GPU box is refused up front (exit 2), not left to fail inside RCCL
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("NM_DIST_BACKEND")
+        r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 2 and "HIP device(s) visible" in r.stderr
+
+
+def test_train_py_called_directly_starts_its_own_ranks(tmp_path):
+    env = dict(os.environ, NM_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "train.py"), "--gpus", "2", "-e", "512", "--iters", "2"], cwd=str(tmp_path), env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
+    assert len([l for l in r.stdout.splitlines() if l.startswith("it ")]) == 2
+    assert "replicas: 2 ranks, max |parameter difference to rank 0| = 0.000e+00" in r.stdout
+
+
 def test_two_rank_bench_times_a_collective():
     env = dict(os.environ, NM_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

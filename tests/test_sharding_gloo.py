@@ -148,3 +148,34 @@ def test_eight_rank_gather_is_ordered_by_global_env_id():
         assert p.exitcode == 0
     assert [(r[1], r[2]) for r in res] == [(g * 4096, (g + 1) * 4096) for g in range(8)]
     assert all(r[3] and r[4] for r in res)
+
+
+def test_self_launch_starts_the_ranks_as_children_and_relays_status(tmp_path):
+    """`python bench.py --gpus N` without torch.distributed.run: the launcher bench.py / train.py use starts N ranks as
+    child processes, the ranks rendezvous on 127.0.0.1, rank 0's output is the job's output and the children's status is the job's status.
+    Here on CPU tensors over gloo; without the rehearsal switch a job with more ranks than HIP devices is refused with exit code 2."""
+    import subprocess
+    script = tmp_path / "ranks.py"
+    script.write_text(
+        "import os, sys, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([float(dist.get_rank() + 1)])\n"
+        "dist.all_reduce(t)\n"
+        "if dist.get_rank() == 0: print('SUM', int(t.item()), sys.argv[1:], flush=True)\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(3 if '--fail' in sys.argv else 0)\n")
+    drv = ("import sys; sys.path.insert(0, %r); from nightmare_rl_amd.distributed import self_launch; "
+           "raise SystemExit(self_launch(%r, sys.argv[1:], 2))" % (ROOT, str(script)))
+    env = dict(os.environ, NM_DIST_BACKEND="gloo")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-c", drv, "--x", "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "SUM 3 ['--x', '1']" in r.stdout
+    r = subprocess.run([sys.executable, "-c", drv, "--fail"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    if torch.cuda.device_count() < 2:
+        env.pop("NM_DIST_BACKEND")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 2 and "HIP device(s) visible" in r.stderr

@@ -1,0 +1,81 @@
+"""The RCCL legs of the multi-GPU path executed for real on the one-GPU box: a world-size-1 `nccl` (= RCCL) process group on cuda:0.
+Started as a child process by tests/test_00_bench_multirank.py. What runs over RCCL here is exactly what the N>1 job runs:
+  * `init_process_group("nccl", device_id=...)` as bench.py / train.py call it,
+  * `gather_returns` on a device tensor (`all_gather_into_tensor`), equal-sized and ragged layout,
+  * the 60 KB gradient | KL all-reduce inside `FusedUpdate.minibatch_data_parallel`, whose result at world size 1 must be bit-identical
+    to the single-process `minibatch`,
+  * `global_advantage_stats` (3-float all-reduce), broadcast of the initial parameters (runner), barrier.
+Prints RCCL_PROBE_OK and the number of collectives issued."""
+import copy
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from nightmare_rl_amd.distributed import gather_returns, global_advantage_stats   # noqa: E402
+from nightmare_rl_amd.rl import ActorCritic                                       # noqa: E402
+from nightmare_rl_amd.rl.fused import FusedUpdate                                 # noqa: E402
+
+
+def main():
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29541")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    assert dist.get_backend() == "nccl" and dist.get_world_size() == 1
+    ncoll = 0
+    dist.barrier()
+    ncoll += 1
+    # the returns all-gather, forced through the collective although one rank could short-cut it
+    r = torch.arange(4096, device=dev, dtype=torch.float32) * 0.25
+    g = gather_returns(r, total_envs=4096, force=True)
+    ncoll += 1
+    assert g.data_ptr() != r.data_ptr() and torch.equal(g, r)
+    g = gather_returns(r[:4001].contiguous(), force=True)          # sizes exchanged first (all_gather of the counts), then the data
+    ncoll += 2
+    assert torch.equal(g, r[:4001])
+    m, s = global_advantage_stats(r, force=True)
+    ncoll += 1
+    torch.testing.assert_close(m, r.mean())
+    torch.testing.assert_close(s, r.std())
+    # the data-parallel mini-batch: local gradient, ONE all-reduce of gradient | KL over RCCL, the step
+    torch.manual_seed(11)
+    ac = ActorCritic(66, 66, 18, actor_hidden_dims=[54, 42, 30], critic_hidden_dims=[54, 42, 30], activation="elu", init_noise_std=0.8).to(dev)
+    for p in ac.parameters():
+        dist.broadcast(p.data, 0)
+        ncoll += 1
+    ref = copy.deepcopy(ac)
+    opt, ropt = torch.optim.Adam(ac.parameters(), lr=1e-3), torch.optim.Adam(ref.parameters(), lr=1e-3)
+    fu, rfu = FusedUpdate(ac, opt, dev, lr=1e-3), FusedUpdate(ref, ropt, dev, lr=1e-3)
+    hp = dict(clip=0.2, value_coef=1.0, entropy_coef=0.0015, clip_value=True, desired_kl=0.01, adaptive=True, max_grad_norm=1.0)
+    B = 4096 + 64
+    gen = torch.Generator(device=dev).manual_seed(3)
+    for it in range(3):
+        rn = lambda *sh: torch.randn(*sh, device=dev, generator=gen)
+        obs = rn(B, 66)
+        with torch.no_grad():
+            old_mu = ref.actor(obs) + 0.05 * rn(B, 18)
+            old_sigma = (ref.std * (1 + 0.05 * rn(18))).expand(B, 18).contiguous()
+            actions = old_mu + old_sigma * rn(B, 18)
+            old_logp = torch.distributions.Normal(old_mu, old_sigma).log_prob(actions).sum(-1)
+            tv = ref.critic(obs).squeeze(-1) + 0.3 * rn(B)
+        batch = (obs, actions, tv, rn(B), tv + rn(B), old_logp, old_mu, old_sigma)
+        fu.minibatch_data_parallel(*batch, hp=hp, world=1)
+        ncoll += 1
+        rfu.minibatch(*batch, hp)
+        st, rst = fu.read_state(), rfu.read_state()
+        assert st["lr"] == rst["lr"] and st["kl"] == rst["kl"], (st, rst)
+        assert torch.equal(fu.flat, rfu.flat) and torch.equal(fu.m, rfu.m) and torch.equal(fu.v, rfu.v), "RCCL all-reduce at world size 1 changed the step"
+    torch.cuda.synchronize()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"RCCL_PROBE_OK collectives={ncoll} nccl_version={'.'.join(map(str, torch.cuda.nccl.version()))}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """train.py - the reference's training entry point (reference train.py:1-54) on the MI355X backend.
 Same flags (-r resume, -v render [rejected: no viewer], -n num_threads [accepted, unused], -e envs, -p resume_path) plus
---iters / --seed. Multi-GPU: python -m torch.distributed.run --nproc-per-node G train.py -e <total envs>."""
+--iters / --seed / --gpus. Multi-GPU: `python train.py --gpus G -e <total envs>` (starts its G ranks as child processes) or
+`python -m torch.distributed.run --nproc-per-node G train.py -e <total envs>`."""
 import argparse
 import datetime
 import os
@@ -24,7 +25,14 @@ def main():
     ap.add_argument("-p", "--resume_path", type=str, default=None, dest="resume_path")
     ap.add_argument("--iters", type=int, default=None, help="learning iterations (default: cfg.runner.max_iterations)")
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks (one per GPU); without torch.distributed.run, train.py starts them itself")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus is not None and args.gpus > 1:
+        # called directly: the ranks become child processes of this one, which has not touched the GPU (and leaves with their status)
+        import sys
+        from nightmare_rl_amd.distributed import self_launch
+        raise SystemExit(self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
