@@ -103,9 +103,16 @@ def load_stl(path, scale):
     assert len(raw) == 84 + 50 * n, f"{path}: not a binary STL"
     rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), offset=84, count=n)
     tri = (rec["v"].astype(np.float32) * np.asarray(scale, dtype=np.float32)).reshape(-1, 3)
-    uniq, inv = np.unique(tri, axis=0, return_inverse=True)
-    faces = inv.reshape(-1, 3)
-    return uniq.astype(np.float64), faces
+    # Repeated vertices are removed IN FILE ORDER: the i-th distinct vertex is the i-th one to appear in the triangle list (MuJoCo's
+    # RemoveRepeated compresses the vertex array in place, it does not sort it). The order matters downstream: qhull's facet list - and
+    # with it the neighbour order of the hull graph, which decides WHICH <= 3 extra plane-mesh contacts are kept - depends on the order
+    # of its input points. (np.unique alone would hand back the vertices sorted by coordinate.)
+    uniq, first, inv = np.unique(tri, axis=0, return_index=True, return_inverse=True)
+    order = np.argsort(first, kind="stable")         # distinct vertices by first occurrence
+    rank = np.empty(len(order), dtype=np.int64)
+    rank[order] = np.arange(len(order))
+    faces = rank[np.asarray(inv).reshape(-1)].reshape(-1, 3)
+    return uniq[order].astype(np.float64), faces
 
 
 def mesh_props(V, F, legacy=True):

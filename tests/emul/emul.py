@@ -8,7 +8,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(HERE, "libnm_emul.so")
 SRC = [os.path.join(HERE, "nm_emul.cpp")] + [os.path.join(HERE, "..", "..", "nightmare_rl_amd", "csrc", f)
-                                             for f in ("nm_core.h", "simt.h", "nm_host_model.h")]
+                                             for f in ("nm_core.h", "simt.h", "nm_host_model.h", os.path.join("..", "model", "nm_model_data.h"))]
 
 
 def build(force=False):
