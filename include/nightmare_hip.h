@@ -211,6 +211,37 @@ int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream
  * reset_sums != 0 clears the two loss sums and the count afterwards. Synchronises the stream. */
 int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream);
 
+/* ---- The collection loop of rsl_rl v1.0.2 OnPolicyRunner.learn (`for i in range(num_steps_per_env): actions = alg.act(obs, critic_obs);
+ * obs, _, rewards, dones, infos = env.step(actions); alg.process_env_step(rewards, dones, infos)`; caller reference train.py:54, horizon
+ * envs/nightmare_v3_config.py:135) as ONE launch of `steps` steps: every wavefront keeps its two envs for the whole rollout and evaluates
+ * the policy itself between two physics steps (no launch per step, no wait for the step's slowest env). Networks of the reference's shape
+ * (envs/nightmare_v3_config.py:105-109; nm_rollout_supported) on the fp32 env only. Results per step are those of the step-by-step path
+ * nm_rollout_act + nm_step + nm_ppo_record: bit-identical observations / actions / values / log-probabilities / rewards / dones in the storage
+ * (sums that go through float atomics - fin3, ep_acc, ep_stats - agree to rounding). All pointers are device memory except the dims. */
+typedef struct {
+  int32_t steps;                       /* K, at most the episode length in steps */
+  const float* params_flat_dev;        /* actor W0 b0 W1 b1 ..., critic W0 b0 ..., std[18] (the flat vector of nm_ppo_*) */
+  uint64_t seed;                       /* action noise: counter generator keyed by (seed, *iter_dev, step, env, action pair) like nm_ppo_sample */
+  const int64_t* iter_dev;
+  const float* obs0_dev;               /* [N,66] the observation the first act sees (the env's current observation) */
+  float* obs_final_dev;                /* [N,66] receives the observation after the last step (may alias obs0_dev) */
+  int64_t* episode_length_dev;         /* [N] episode_length_buf, in/out */
+  float* rew_dev; int64_t* done_dev;   /* [N] the env's reward / reset buffers: hold the last step's values afterwards */
+  float* time_outs_dev;                /* [N] extras['time_outs'] in/out (NULL: no time-out bootstrap), ep_stats_dev [NM_NUM_REWARDS] extras['episode'] in/out */
+  float* ep_stats_dev;
+  float *s_obs, *s_actions, *s_logp, *s_values, *s_mu, *s_sigma, *s_rewards;   /* rollout storage rows [K,N,66] [K,N,18] [K,N] [K,N] [K,N,18] [K,N,18] [K,N] */
+  unsigned char* s_dones;              /* [K,N] */
+  float gamma;                         /* time-out bootstrap: rewards += gamma * value * extras['time_outs'] (PPO.process_env_step) */
+  float *cur_ret, *cur_len, *fin3;     /* [N] [N] [3]: as nm_ppo_record */
+  const int32_t* ep_idx_dev; int32_t n_ep; float* ep_acc_dev;   /* ep_acc[i] += extras['episode'][ep_idx[i]] after every step, i < n_ep <= NM_NUM_REWARDS */
+} nm_rollout_args;
+/* 1 if nm_rollout / nm_rollout_act are compiled for these networks (dims = {n_obs, h1, h2, h3, n_out}, HOST arrays) */
+int nm_rollout_supported(const int32_t* actor_dims, const int32_t* critic_dims, int32_t n_layers);
+int nm_rollout(nm_env* env, const nm_rollout_args* args, void* stream);
+/* PPO.act alone, on the code the rollout's waves run (one wave = two envs): the per-step counterpart of nm_rollout. Arguments as nm_ppo_act. */
+int nm_rollout_act(nm_env* env, const float* params_flat_dev, const float* obs_dev, uint64_t seed, const int64_t* iter_dev, int32_t step,
+                   float* actions_dev, float* logp_dev, float* values_dev, float* mu_dev, float* sigma_dev, float* obs_store_dev, void* stream);
+
 /* ---- scripted gait / IK engine (reference nikengine/engine.py; caller custom_play.py:49-76), batched over envs ----
  * One handle = num_envs independent EngineNode objects (engine.py:660-677), all in IdleState. */
 typedef struct nm_nik nm_nik;

@@ -9,6 +9,7 @@
 
 #include "../../include/nightmare_hip.h"
 #include "nm_host_model.h"
+#include "nm_rollout.h"
 
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
@@ -154,6 +155,7 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
 #endif
 }
 
+
 // reset_idx (reference envs/nightmare_v3_env.py:335-371): one thread per env to reset
 template <class real>
 __global__ void k_reset(nm::Model<real> M, nm::Args<real> A, const int32_t* ids, int n) {
@@ -226,6 +228,9 @@ struct nm_env {
   virtual void set_dbg(void* p) = 0;
   virtual void set_ret_acc(float* p) = 0;
   virtual int invalidate_time_outs(hipStream_t s) = 0;
+  virtual int rollout(const nm_rollout_args* r, hipStream_t s) = 0;
+  virtual int rollout_act(const float* flat, const float* obs, uint64_t seed, const int64_t* iter_dev, int step, float* actions, float* logp, float* values,
+                          float* mu, float* sigma, float* obs_store, hipStream_t s) = 0;
   virtual int profiling(int on, double* sum_ms, int64_t* count) = 0;
   virtual void set_ablate(int m) = 0;
   virtual int set_noise(const double* vec) = 0;
@@ -500,6 +505,71 @@ template <class real> struct Env : nm_env {
     if (nbad) *nbad = (int32_t)tmp[49];
     return 0;
   }
+
+  // ---- K-step rollout with the policy in the wave (nm_rollout; fp32 two-env waves and the reference's network shape only)
+  float *roll_wp = nullptr, *roll_bp = nullptr;
+  real* roll_sum = nullptr;
+  int *roll_cnt = nullptr, *roll_to = nullptr;
+  int roll_cap = 0;
+  typedef nmr::RefShape RS;
+  int roll_pack(const float* flat, hipStream_t s) {
+    if (!roll_wp && (dalloc(&roll_wp, (size_t)RS::nfrag() * 256) || dalloc(&roll_bp, (size_t)RS::nbias()))) return 1;
+    if (nmr::launch_pack(flat, roll_wp, roll_bp, s)) return fail("nm_rollout: packing the policy failed to launch");
+    return 0;
+  }
+  int rollout_act(const float* flat, const float* obs, uint64_t seed, const int64_t* iter_dev, int step, float* actions, float* logp, float* values,
+                  float* mu, float* sigma, float* obs_store, hipStream_t s) override {
+    HIPCHK(hipSetDevice(device));
+    if (!flat || !obs || !iter_dev || !actions || !logp || !values || !mu || !sigma) return fail("nm_rollout_act: NULL pointer");
+    if (roll_pack(flat, s)) return 1;
+    nmr::ActOut o{actions, logp, values, mu, sigma, obs_store};
+    if (nmr::launch_act(roll_wp, roll_bp, flat + RS::stdoff(), obs, N, seed, iter_dev, step, o, s)) return fail("nm_rollout_act: launch failed");
+    return 0;
+  }
+  int rollout(const nm_rollout_args* r, hipStream_t s) override {
+    HIPCHK(hipSetDevice(device));
+    if constexpr (sizeof(real) == 8 || NM_ENVS_PER_WAVE != 2) {
+      return fail("nm_rollout: the fused rollout runs on the fp32 kernel (two envs per wave) only");
+    } else {
+      if (!r) return fail("nm_rollout: args is NULL");
+      const int K = r->steps;
+      if (K < 1 || K > 4096) return fail("nm_rollout: steps must be in 1..4096");
+      if ((double)K > (double)M.max_ep_len) return fail("nm_rollout: more steps than an episode has (an env may time out once per rollout)");
+      if (!r->params_flat_dev || !r->iter_dev || !r->obs0_dev || !r->obs_final_dev || !r->episode_length_dev || !r->rew_dev || !r->done_dev || !r->s_obs ||
+          !r->s_actions || !r->s_logp || !r->s_values || !r->s_mu || !r->s_sigma || !r->s_rewards || !r->s_dones || !r->cur_ret || !r->cur_len || !r->fin3)
+        return fail("nm_rollout: NULL pointer");
+      if (r->n_ep < 0 || r->n_ep > nm::kNREW || (r->n_ep > 0 && (!r->ep_idx_dev || !r->ep_acc_dev || !r->ep_stats_dev))) return fail("nm_rollout: bad episode-statistics arguments");
+      if (rec_env >= 0) return fail("nm_rollout: the state log (nm_set_state_record) needs one launch per step");
+      if (K > roll_cap) {   // per-step accumulators (zero: the slab and hipMalloc'ed blocks are cleared, k_rollout_clear keeps them so)
+        const int cap = (K + 127) & ~127;
+        if (dalloc(&roll_sum, (size_t)cap * nm::kNREW) || dalloc(&roll_cnt, (size_t)cap * 4)) return 1;
+        if (!roll_to && dalloc(&roll_to, (size_t)N)) return 1;
+        roll_cap = cap;
+      }
+      if (roll_pack(r->params_flat_dev, s)) return 1;
+      nm::Args<real> a = A;
+      a.actions = nullptr; a.eplen = r->episode_length_dev; a.obs = r->obs_final_dev; a.rew = r->rew_dev; a.done = r->done_dev; a.timeout_now = timeout_now;
+      a.cmd_u = cmd_u_on ? cmd_u_dev : nullptr;
+      a.physics_only = 0;
+      a.ep_stats = nullptr; a.time_outs = nullptr; a.counters = counters_dev;     // extras are closed by k_rollout_tail
+      a.to_list = nullptr;
+      a.noise_vec = noise_on ? noise_vec_dev : nullptr;
+      a.noise_u = noise_on && noise_u_on ? noise_u_dev : nullptr;
+      a.noise_step = noise_step;
+      noise_step += (uint64_t)K;
+      a.rec = nullptr; a.rec_env = -1; a.dbg = nullptr; a.ret_acc = nullptr;
+      nmr::RollArgs R;
+      R.K = K; R.wp = (const nmr::f32x4*)roll_wp; R.bp = roll_bp; R.stdv = r->params_flat_dev + RS::stdoff();
+      R.seed = r->seed; R.iter_dev = r->iter_dev; R.obs0 = r->obs0_dev; R.obs_final = r->obs_final_dev;
+      R.s_obs = r->s_obs; R.s_actions = r->s_actions; R.s_logp = r->s_logp; R.s_values = r->s_values; R.s_mu = r->s_mu; R.s_sigma = r->s_sigma;
+      R.s_rewards = r->s_rewards; R.s_dones = r->s_dones; R.cur_ret = r->cur_ret; R.cur_len = r->cur_len; R.fin3 = r->fin3;
+      R.st_sum = roll_sum; R.st_cnt = roll_cnt; R.to_step = roll_to;
+      nmr::TailArgs ta{N, K, roll_sum, roll_cnt, roll_to, r->ep_stats_dev, r->time_outs_dev, M.ep_len_s, counters_dev, r->gamma, r->s_values, r->s_rewards,
+                       r->ep_idx_dev, r->n_ep, r->ep_acc_dev, A.to_owner};
+      if (nmr::launch_rollout(M_dev, a, R, ta, s)) return fail("nm_rollout: launch failed");
+      return 0;
+    }
+  }
   void set_dbg(void* p) override { A.dbg = (real*)p; }
   void set_ret_acc(float* p) override { A.ret_acc = p; }
   int invalidate_time_outs(hipStream_t s) override {
@@ -612,6 +682,19 @@ int nm_get_counters(nm_env* env, int64_t* out2) { NEED(env); return env->counter
 int nm_set_debug_buffer(nm_env* env, void* dbg) { NEED(env); env->set_dbg(dbg); return 0; }
 int nm_set_return_accumulator(nm_env* env, float* acc) { NEED(env); env->set_ret_acc(acc); return 0; }
 int nm_invalidate_time_outs(nm_env* env, void* stream) { NEED(env); return env->invalidate_time_outs((hipStream_t)stream); }
+int nm_rollout_supported(const int32_t* actor_dims, const int32_t* critic_dims, int32_t n_layers) {
+  typedef nmr::RefShape RS;
+  if (!actor_dims || !critic_dims || n_layers != RS::NL) return 0;
+  if (actor_dims[0] != RS::I || critic_dims[0] != RS::I) return 0;
+  for (int l = 0; l < RS::NL; l++)
+    if (actor_dims[l + 1] != RS::aout(l) || critic_dims[l + 1] != RS::cout(l)) return 0;
+  return 1;
+}
+int nm_rollout(nm_env* env, const nm_rollout_args* args, void* stream) { NEED(env); return env->rollout(args, (hipStream_t)stream); }
+int nm_rollout_act(nm_env* env, const float* flat, const float* obs, uint64_t seed, const int64_t* iter_dev, int32_t step, float* actions, float* logp,
+                   float* values, float* mu, float* sigma, float* obs_store, void* stream) {
+  NEED(env); return env->rollout_act(flat, obs, seed, iter_dev, step, actions, logp, values, mu, sigma, obs_store, (hipStream_t)stream);
+}
 #ifdef NM_MEASURE   // include/nightmare_hip_measure.h: not part of the shipped ABI
 int nm_set_ablation(nm_env* env, int32_t mask) { NEED(env); env->set_ablate(mask); return 0; }
 #endif

@@ -214,6 +214,55 @@ class NightmareV3Env:
             self._fill_extras()
         return self.obs_buf, None, self.rew_buf, self.reset_buf, self.extras
 
+    # ------------------------------------------------------------------ K steps per launch with the policy in the env's wave
+    def policy_rollout(self, steps, params_flat, seed, iter_dev, storage, gamma, cur_ret, cur_len, fin, ep=None):
+        """`steps` iterations of rsl_rl's collection loop `act -> env.step -> process_env_step` (OnPolicyRunner.learn; reference
+        train.py:54) as ONE launch (nm_rollout): starts from the current observation, files every transition into `storage` (a
+        RolloutStorage with `steps` rows: observations, actions, values, log-probabilities, mu, sigma, rewards incl. the time-out bootstrap,
+        dones), updates the runner's bookkeeping tensors (cur_ret / cur_len [N], fin [3], and ep = (ep_idx int32, ep_acc) for the running
+        sum of extras['episode']) and leaves the env as `steps` calls of step() would: obs_buf / rew_buf / reset_buf / extras of the last step.
+        params_flat: the flat parameter vector of FusedUpdate (actor W0 b0 ..., critic ..., std)."""
+        if self.cfg.viewer.record_states:
+            raise ValueError("policy_rollout: cfg.viewer.record_states needs one launch per step")
+        T = int(steps)
+        if storage.num_transitions_per_env < T or storage.num_envs != self.num_envs or storage.privileged_observations is not None:
+            raise ValueError("policy_rollout: storage must hold `steps` rows of this env's transitions (no privileged observations)")
+        if self.time_out_buf is not self._to_bound:
+            self._ck(self._L.nm_invalidate_time_outs(self._h, self._stream()))
+            self._to_bound = self.time_out_buf
+        ep_idx, ep_acc = ep if ep is not None else (None, None)
+        a = _lib.NmRolloutArgs()
+        a.steps, a.params_flat_dev, a.seed, a.iter_dev = T, params_flat.data_ptr(), int(seed), iter_dev.data_ptr()
+        a.obs0_dev = self.obs_buf.data_ptr()
+        self._obs_idx ^= 1
+        self.obs_buf = self._obs_pair[self._obs_idx]           # the tensor handed out before the rollout stays what it was
+        a.obs_final_dev = self.obs_buf.data_ptr()
+        a.episode_length_dev = self._eplen().data_ptr()
+        a.rew_dev, a.done_dev = self.rew_buf.data_ptr(), self.reset_buf.data_ptr()
+        a.time_outs_dev = self.time_out_buf.data_ptr() if self.cfg.env.send_timeouts else None
+        a.ep_stats_dev = self._ep_stats.data_ptr()
+        a.s_obs, a.s_actions, a.s_logp, a.s_values = (storage.observations.data_ptr(), storage.actions.data_ptr(), storage.actions_log_prob.data_ptr(),
+                                                       storage.values.data_ptr())
+        a.s_mu, a.s_sigma, a.s_rewards, a.s_dones = storage.mu.data_ptr(), storage.sigma.data_ptr(), storage.rewards.data_ptr(), storage.dones.data_ptr()
+        a.gamma = float(gamma)
+        a.cur_ret, a.cur_len, a.fin3 = cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr()
+        a.ep_idx_dev, a.n_ep, a.ep_acc_dev = (ep_idx.data_ptr(), int(ep_idx.numel()), ep_acc.data_ptr()) if ep_idx is not None else (None, 0, None)
+        self._ck(self._L.nm_rollout(self._h, C.byref(a), self._stream()))
+        self._keep_rollout = (params_flat, iter_dev, storage, cur_ret, cur_len, fin, ep_idx, ep_acc)
+        self.common_step_counter += T
+        storage.step = T
+        if "episode" not in self.extras:
+            self._fill_extras()
+        return self.obs_buf
+
+    def policy_act(self, params_flat, obs, seed, iter_dev, step, storage):
+        """PPO.act as one launch of the rollout's wave code (nm_rollout_act): the per-step counterpart of policy_rollout."""
+        s = int(step)
+        self._ck(self._L.nm_rollout_act(self._h, params_flat.data_ptr(), obs.data_ptr(), int(seed), iter_dev.data_ptr(), s, storage.actions[s].data_ptr(),
+                                        storage.actions_log_prob[s].data_ptr(), storage.values[s].data_ptr(), storage.mu[s].data_ptr(),
+                                        storage.sigma[s].data_ptr(), storage.observations[s].data_ptr(), self._stream()))
+        return storage.actions[s]
+
     def actions_from_joint_targets(self, targets):
         """Policy-space actions that make the servo track absolute joint targets (the hook at reference :186):
         step() commands (action_scale*a - default_pos - dof_pos)*p_gain (:152-156,:183-188), so a = (q* + default_pos)/action_scale.

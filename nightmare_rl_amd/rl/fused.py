@@ -117,6 +117,24 @@ class FusedCollector:
                                          storage.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(), eps, epi, n_ep, epa, stream))
         storage.step += 1
 
+    def can_rollout(self, env):
+        """Can the whole rollout run as ONE launch inside the env's own waves (nm_rollout)? Needs this repo's fp32 env on the same device,
+        networks of the compiled shape next to a FusedUpdate (its flat parameter vector is what the kernel reads), no privileged observations."""
+        if self.update is None or not hasattr(env, "policy_rollout") or getattr(env, "_dtype", None) != _lib.DTYPE_F32:
+            return False
+        if env.num_envs != self.N or torch.device(env.device) != self.device or env.cfg.viewer.record_states or env.get_privileged_observations() is not None:
+            return False
+        a = (C.c_int32 * (len(self.a_lin) + 1))(self.a_lin[0].in_features, *[m.out_features for m in self.a_lin])
+        c = (C.c_int32 * (len(self.c_lin) + 1))(self.c_lin[0].in_features, *[m.out_features for m in self.c_lin])
+        return bool(self._L.nm_rollout_supported(a, c, len(self.a_lin)))
+
+    def rollout(self, env, storage, steps, gamma, cur_ret, cur_len, fin, ep=None):
+        """`steps` x (PPO.act, env.step, PPO.process_env_step + the runner's bookkeeping) as one launch; returns the last observation.
+        Same noise keys as act(): (seed, iteration set by refresh(), step, env, action pair)."""
+        self.drop_pending()
+        storage.clear()
+        return env.policy_rollout(steps, self.update.flat, self.seed, self.iter_dev, storage, gamma, cur_ret, cur_len, fin, ep=ep)
+
     def drop_pending(self):
         """Forget a deferred record without launching it: the storage it would write into has been cleared (end of an update, a failed
         graph capture) - its arguments point at a step that no longer exists."""

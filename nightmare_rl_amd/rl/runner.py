@@ -79,6 +79,18 @@ class OnPolicyRunner:
             fin.zero_()
             if ep_acc is not None:
                 ep_acc.zero_()
+            if one_launch:
+                # the whole loop below inside the env's own waves: policy, step, record, K times, no launch in between (nm_rollout)
+                if state.get("ep_idx") is None:
+                    keys = sorted(env.extras["episode"])
+                    state["ep_keys"] = keys
+                    state["ep_idx"] = torch.tensor([env._stat_names.index(k[4:]) for k in keys], device=dev, dtype=torch.int32)
+                    state["ep_idx64"] = state["ep_idx"].long()
+                if ep_acc is None:
+                    ep_acc = torch.zeros(len(state["ep_keys"]), device=dev)
+                o = alg.fused.rollout(env, alg.storage, T, alg.gamma, cur_ret, cur_len, fin, ep=(state["ep_idx"], ep_acc))
+                state["obs"] = state["critic_obs"] = o
+                return
             for _ in range(T):
                 actions = alg.act(o, co)
                 o, priv_, rewards, dones, infos = env.step(actions)
@@ -124,7 +136,10 @@ class OnPolicyRunner:
             state["obs"], state["critic_obs"] = o, co
 
         on_gpu = torch.device(dev).type == "cuda"
-        want_graph = bool(self.cfg.get("graph_rollout", True)) and torch.device(dev).type == "cuda" and hasattr(env, "_h") \
+        one_launch = bool(self.cfg.get("fused_rollout", True)) and getattr(alg, "fused", None) is not None and priv is None \
+            and alg.fused.can_rollout(env) and T <= int(env.max_episode_length)
+        self.rollout_mode = "one launch (nm_rollout)" if one_launch else "per-step launches"
+        want_graph = not one_launch and bool(self.cfg.get("graph_rollout", True)) and torch.device(dev).type == "cuda" and hasattr(env, "_h") \
             and not getattr(env, "add_noise", False) and not getattr(getattr(env.cfg, "viewer", None), "record_states", False)
         graph = None
         ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else (None, None)

@@ -21,6 +21,12 @@ def test_rccl_world_size_one_probe():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "NM_DIST_BACKEND"):
         env.pop(k, None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "tools", "rccl_probe.py")], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    try:      # the whole transcript for the record (gpurun_out/ is what comes back from the GPU box)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "rccl_probe.log"), "w") as f:
+            f.write(r.stdout + "\n---- stderr ----\n" + r.stderr)
+    except OSError:
+        pass
     assert r.returncode == 0, (r.stdout[-1000:], r.stderr[-3000:])
     assert "RCCL_PROBE_OK" in r.stdout
     print(r.stdout.strip().splitlines()[-1])
