@@ -337,7 +337,7 @@ NM_FN void nm_stamp(int k) {   // k = -1 starts the clock, k = 10 is the last st
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // exact attribution: outstanding loads belong to the segment that issued them
 #endif
   unsigned long long n = __builtin_amdgcn_s_memtime();
-  if (threadIdx.x == 0) {
+  if (NM_TID == 0) {
     if (k < 0) for (int i = 0; i < 16; i++) acc[i] = 0;
     else acc[k] += n - tl;
     if (k == 10) for (int i = 0; i < 16; i++) atomicAdd(&g_stamps[i], acc[i]);
@@ -2826,7 +2826,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #ifdef NM_EMUL
     A.stat_cnt[1] += dropped; A.stat_cnt[2] += sh.nwarn;
 #else
-    if (threadIdx.x == 0) { nm_consume(atomicAdd(A.stat_cnt + 1, dropped)); nm_consume(atomicAdd(A.stat_cnt + 2, sh.nwarn)); }
+    if (NM_TID == 0) { nm_consume(atomicAdd(A.stat_cnt + 1, dropped)); nm_consume(atomicAdd(A.stat_cnt + 2, sh.nwarn)); }
 #endif
   }
   if (A.physics_only) return;
@@ -2915,8 +2915,8 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
     for (int k = 0; k < kNREW; k++) A.stat_sum[k] += epsum[0].v[k];
     A.stat_cnt[0] += 1;
 #else
-    if (threadIdx.x < kNREW) nm_consume(atomicAdd(A.stat_sum + threadIdx.x, epsum[0]));
-    if (threadIdx.x == 0) {
+    if (NM_TID < kNREW) nm_consume(atomicAdd(A.stat_sum + NM_TID, epsum[0]));
+    if (NM_TID == 0) {
       nm_consume(atomicAdd(A.stat_cnt, 1));
       if (time_out && A.to_list) nm_consume(atomicExch(A.to_list + atomicAdd(A.nto, 1), env));
     }
@@ -2977,7 +2977,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #ifdef NM_EMUL
         A.feetflags[env] = nf;
 #else
-        if (threadIdx.x == 0) gst1(A.feetflags, env, nf);
+        if (NM_TID == 0) gst1(A.feetflags, env, nf);
 #endif
       }
     }
@@ -3037,7 +3037,7 @@ template <class real> NM_FN void env_finish(Sh<real>& sh, const Model<real>& M, 
 #ifdef NM_EMUL
   const bool lane0 = true;
 #else
-  const bool lane0 = threadIdx.x == 0;
+  const bool lane0 = NM_TID == 0;
 #endif
   if (lane0) {
     gst1(A.eplen, env, eplen);
@@ -3192,7 +3192,7 @@ template <class real, class Pub> NM_FN void env_finish2(ShW<real, 2>& w, const M
     A.stat_cnt[1] += dropped;
     for (int hh = 0; hh < 2; hh++) if (lives[hh]) A.stat_cnt[2] += nwarn.v[32 * hh];
 #else
-    if (threadIdx.x == 0 && dropped) nm_consume(atomicAdd(A.stat_cnt + 1, dropped));
+    if (NM_TID == 0 && dropped) nm_consume(atomicAdd(A.stat_cnt + 1, dropped));
     if (hl == 0 && live && nwarn) nm_consume(atomicAdd(A.stat_cnt + 2, nwarn));
 #endif
   }

@@ -30,7 +30,7 @@ static int fail(const std::string& m) { g_err = m; return 1; }
 // extras: like the reference, 'episode' and 'time_outs' are refreshed only by a step in which >= 1 env reset (env.py:344-371);
 // then the per-step accumulators are cleared for the next launch. One wave, after all others have published.
 template <class real> __device__ __noinline__ void step_tail(const nm::Args<real>& A, real ep_len_s) {
-  const int lane = threadIdx.x;
+  const int lane = NM_TID;
   // This runs behind the launch's last wave, alone: every global access is a full round trip that nothing hides. So the reads are
   // issued in two batches - everything that is addressed by the lane alone, then the two lists those counts index - not one by one.
 #define TAIL_LD(p) __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
@@ -77,28 +77,39 @@ template <class real> __device__ __noinline__ void step_tail(const nm::Args<real
   }
 }
 
+// Waves per workgroup: 1 by default (LDS image private to the wave, no inter-wave synchronisation at all). -DNM_WG_WAVES=w (measurement,
+// DESIGN.md 6.1) packs w waves into one workgroup - w times fewer workgroups for the dispatcher to start - with wave-private env images and
+// ONE shared copy of the model constants and of the launch arguments; the two barriers of the start-up are then real workgroup barriers.
+#ifdef NM_WG_WAVES
+constexpr int kWG = NM_WG_WAVES;
+#else
+constexpr int kWG = 1;
+#endif
 template <class real, int G>
-__global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
-  __shared__ nm::ShW<real, G> sh;
-  __shared__ nm::Model<real> Ms;   // this wave's copy of the model constants
+__global__ void __launch_bounds__(64 * (sizeof(real) == 8 ? 1 : kWG), NM_WAVES_PER_SIMD) k_env_step(const nm::Model<real>* __restrict__ Mp, nm::Args<real> A) {
+  constexpr int kWG = sizeof(real) == 8 ? 1 : ::kWG;     // the fp64 verification build keeps one wave per workgroup
+  __shared__ nm::ShW<real, G> shs[kWG];
+  __shared__ nm::Model<real> Ms;   // this workgroup's copy of the model constants
   __shared__ nm::Args<real> As;    // ... and of the launch arguments: ~30 pointers would otherwise pin 60 SGPRs for the whole kernel
+  nm::ShW<real, G>& sh = shs[kWG == 1 ? 0 : (int)(threadIdx.x >> 6)];
   // XCD-aware block -> wave mapping: the dispatcher deals workgroups round-robin over the 8 XCDs (block b runs on XCD b % 8), each with
   // its own L2. Consecutive envs share cache lines (rows of 100 / 96 / 72 bytes), so each XCD takes a CONTIGUOUS eighth of the waves:
   // a line's bytes are then written through one L2 instead of being merged in memory from two.
   int wave = blockIdx.x;
 #ifndef NM_NO_XCD_MAP
   {
-    const int nwx = (int)gridDim.x >> 3;          // waves per XCD (the remainder, if any, keeps the identity mapping)
+    const int nwx = (int)gridDim.x >> 3;          // workgroups per XCD (the remainder, if any, keeps the identity mapping)
     if (A.nxcd == 8 && wave < (nwx << 3)) wave = (wave & 7) * nwx + (wave >> 3);   // other partition modes (CPX, DPX): identity
   }
 #endif
-  if (wave * G >= A.N) return;
+  if (kWG > 1) wave = wave * kWG + (int)(threadIdx.x >> 6);
 #ifdef NM_MEASURE
   if (A.ablate & 512) return;      // measurement only: the empty launch
 #endif
   const unsigned long long t_start = A.dbg ? __builtin_amdgcn_s_memtime() : 0ull;
-  As = A;
+  if (kWG == 1 || threadIdx.x < 64) As = A;
   __syncthreads();
+  if (wave * G >= A.N) return;     // (a wave that has left does not count for the barrier of the model copy below)
   // the model copy (L2 -> LDS) runs inside the load stage, after the env rows' HBM reads have been issued: one start-up round trip, not two
   auto copy_model = [&]() {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(Mp);
@@ -106,27 +117,29 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
     constexpr int kWords = (int)(sizeof(nm::Model<real>) / 4);
     uint32_t tmp[(kWords + 63) / 64];
 #pragma unroll
-    for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; tmp[k] = i < kWords ? src[i] : 0u; }
+    for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = NM_TID + 64 * k; tmp[k] = i < kWords ? src[i] : 0u; }
+    if (kWG == 1 || threadIdx.x < 64) {     // one wave fills the workgroup's copy
 #pragma unroll
-    for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = threadIdx.x + 64 * k; if (i < kWords) dst[i] = tmp[k]; }
+      for (int k = 0; k < (kWords + 63) / 64; k++) { const int i = NM_TID + 64 * k; if (i < kWords) dst[i] = tmp[k]; }
+    }
     __syncthreads();
   };
   // Two-level ticket for "which wave closes the step": waves draw from their group's counter, the last wave of a group from the top
   // counter - at most 64 + 32 same-address atomics in a row instead of gridDim.x. A wave draws its group ticket as soon as everything
   // it contributes to the bookkeeping is published (inside the epilogue, before rewards and observation), so the round trip of that
   // atomic is off the critical path of the wave that finishes last.
-  const int nw = (int)gridDim.x, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
+  const int nw = (int)gridDim.x * kWG, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
   const int gsize = min(nm::kTicketGroup, nw - grp * nm::kTicketGroup);
   int ticket = 0, top = 0;
   int stage = 0;                       // 0: nothing drawn, 1: group ticket drawn, 2: group ticket resolved (and the top one drawn if this wave closes its group)
   bool closes_group = false;
   auto draw = [&](int phase) {
     if (phase == 0) {
-      if (threadIdx.x == 0) ticket = atomicAdd(As.wave_done + (grp + 1) * nm::kTicketStride, 1);
+      if (NM_TID == 0) ticket = atomicAdd(As.wave_done + (grp + 1) * nm::kTicketStride, 1);
       stage = 1;
     } else {
       closes_group = __builtin_amdgcn_readfirstlane(ticket) == gsize - 1;
-      if (closes_group && threadIdx.x == 0) {
+      if (closes_group && NM_TID == 0) {
         As.wave_done[(grp + 1) * nm::kTicketStride] = 0;     // every member has drawn: re-arm for the next launch
         top = atomicAdd(As.wave_done + nm::kTicketTop, 1);
       }
@@ -134,7 +147,7 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_step(const nm::Mo
     }
   };
   nm::wave_step<real, G>(sh, Ms, As, wave, copy_model, draw);
-  if (As.dbg && threadIdx.x == 0) {   // debug buffer only: start / end clock of this wave as exact 24-bit pieces (scripts/wavetimes.py)
+  if (As.dbg && NM_TID == 0) {   // debug buffer only: start / end clock of this wave as exact 24-bit pieces (scripts/wavetimes.py)
     const unsigned long long t_end = __builtin_amdgcn_s_memtime();
     real* d = As.dbg + (size_t)(wave * G) * nm::kDbgN + 250;
     d[0] = (real)(unsigned)(t_start & 0xFFFFFF); d[1] = (real)(unsigned)((t_start >> 24) & 0xFFFFFF);
@@ -384,7 +397,8 @@ template <class real> struct Env : nm_env {
       HIPCHK(hipEventRecord(e0, s));
     }
     constexpr int G = sizeof(real) == 8 ? 1 : NM_ENVS_PER_WAVE;  // the fp64 verification build keeps one env per wave (LDS)
-    hipLaunchKernelGGL((k_env_step<real, G>), dim3((N + G - 1) / G), dim3(64), 0, s, (const nm::Model<real>*)M_dev, a);
+    constexpr int W = sizeof(real) == 8 ? 1 : kWG;
+    hipLaunchKernelGGL((k_env_step<real, G>), dim3((N + G * W - 1) / (G * W)), dim3(64 * W), 0, s, (const nm::Model<real>*)M_dev, a);
     HIPCHK(hipGetLastError());
     if (prof_on) HIPCHK(hipEventRecord(e1, s));
     return 0;

@@ -24,7 +24,14 @@ namespace simt {
 template <class T> using V = T;
 using VB = bool;
 
-NM_FN int lane_id() { return (int)threadIdx.x; }
+// lane of the thread inside its wavefront. One wave per workgroup (the default): the thread index itself. -DNM_WG_WAVES=w packs w waves
+// into a workgroup (fewer workgroups for the dispatcher to start; LDS slices stay wave-private): the low six bits.
+#ifdef NM_WG_WAVES
+#define NM_TID ((int)(threadIdx.x & 63))
+#else
+#define NM_TID ((int)threadIdx.x)
+#endif
+NM_FN int lane_id() { return NM_TID; }
 template <class T> NM_FN T sel(bool c, T a, T b) { return c ? a : b; }
 NM_FN float vsqrt(float x) { return sqrtf(x); }
 NM_FN double vsqrt(double x) { return sqrt(x); }
@@ -82,13 +89,13 @@ NM_FN double rdlane(double x, int l) {
 // the `lane == l` mask is recomputed here (v_cmp + v_cndmask) instead of being hoisted out of the solver's
 // iteration loops by LICM, where 64+ live masks (2 SGPRs each) spill the scalar register file.
 template <class T> NM_FN T wrlane(T x, T v, int l) {
-  int ln = (int)threadIdx.x;
+  int ln = NM_TID;
   asm volatile("" : "+v"(ln));
   return ln == l ? v : x;
 }
 // lane id that the optimiser cannot see through: compares against it stay inside the loop they are written in (hoisting
 // 64 loop-invariant `lane == i` masks out of the solver sweeps costs 128 SGPRs and spills the scalar file)
-NM_FN int opaque_lane() { int ln = (int)threadIdx.x; asm volatile("" : "+v"(ln)); return ln; }
+NM_FN int opaque_lane() { int ln = NM_TID; asm volatile("" : "+v"(ln)); return ln; }
 template <class T> NM_FN T uniform(T x) { return rdlane(x, 0); }
 NM_FN bool uniform(bool x) { return __builtin_amdgcn_readfirstlane((int)x) != 0; }
 // ---- DPP lane permutations inside a row of 16 lanes (no LDS traffic, ~VALU latency)
@@ -133,7 +140,7 @@ template <class T> NM_FN T hsum32(T x) {
   x = x + dpp<NM_DPP_HALF_MIRROR>(x);
   x = x + dpp<NM_DPP_ROW_MIRROR>(x);
   const T s0 = rdlane(x, 0) + rdlane(x, 16), s1 = rdlane(x, 32) + rdlane(x, 48);
-  return (threadIdx.x & 32) ? s1 : s0;
+  return (NM_TID & 32) ? s1 : s0;
 }
 NM_FN bool wany(bool c) { return __ballot(c) != 0ull; }
 // number of set bits of the wave-uniform mask m below this lane (v_mbcnt)
@@ -182,7 +189,7 @@ template <class T> NM_FN void stsv(T* a, int i, T v, bool m) { if (m) a[i] = v; 
 // masked LDS store without a branch: lanes outside the mask write their value to their own word of a scratch row instead. A masked
 // store compiles to s_and_saveexec / s_cbranch_execz / ds_write / s_or - the end of a scheduling region; this is one v_cndmask on the address.
 template <class T, class S> NM_FN void stsu(T* a, int i, T v, bool m, S* sink) {
-  T* p = m ? a + i : reinterpret_cast<T*>(sink) + threadIdx.x;
+  T* p = m ? a + i : reinterpret_cast<T*>(sink) + NM_TID;
   *p = v;
 }
 // Global-memory accessors. The pointers reach the kernel through an LDS copy of the launch arguments / model struct, so
