@@ -172,7 +172,8 @@ int nm_ppo_record(const float* rew_dev, const int64_t* done_dev, const float* ti
 
 /* ---- PPO mini-batch update (rsl_rl v1.0.2 `algorithms/ppo.py` PPO.update: clipped surrogate + clipped value loss + entropy bonus,
  * adaptive-KL learning rate, gradient-norm clipping, Adam; caller reference train.py:54; hyper-parameters envs/nightmare_v3_config.py:111-128)
- * as five launches per mini-batch (forward/backward, reduce, scalars, Adam, pack) with no host synchronisation. actor_dims / critic_dims = {n_obs, h1, ..., n_out} (same depth, same
+ * as two launches per mini-batch (forward/backward; then partial-gradient reduction, gradient-norm clip, KL-adaptive learning rate, Adam and
+ * the repacking of the weights in one launch with one grid barrier) with no host synchronisation. actor_dims / critic_dims = {n_obs, h1, ..., n_out} (same depth, same
  * observation, critic output 1, ELU). The parameters live in ONE caller-owned flat device vector in the order
  * actor W0 b0 W1 b1 ..., critic W0 b0 ..., std[A] (W row-major [out, in] as torch.nn.Linear); Adam's moments in two more such vectors. */
 typedef struct nm_ppo nm_ppo;
@@ -190,6 +191,17 @@ int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_
                      const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* target_values,
                      int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
                      int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
+/* nm_ppo_minibatch with the mini-batch given as ROW NUMBERS into the whole rollout (rsl_rl's mini_batch_generator gathers obs[batch_idx], ...;
+ * here the forward / backward kernel gathers the rows itself, nothing is copied): row i of the mini-batch is row rows_dev[i] (int32, device)
+ * of the [T*N, .] arrays. rows_dev == NULL = rows 0..B-1 (nm_ppo_minibatch). */
+int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
+                          const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* target_values,
+                          const int32_t* rows_dev, int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
+                          int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
+/* The mini-batch order of one PPO.update (rsl_rl v1.0.2 mini_batch_generator: indices = torch.randperm(num_mini_batches * mini_batch_size)):
+ * out_dev[i] (int32) = image of i under a pseudo-random permutation of 0..n-1 keyed by (seed, counter) - a cycle-walked Feistel network,
+ * one launch, no sort. */
+int nm_ppo_permutation(int32_t* out_dev, int32_t n, uint64_t seed, uint64_t counter, void* stream);
 /* 1 if the network runs on the compiled register-resident kernels (the reference's 66 -> 54 -> 42 -> 30 -> 18 | 1 shape), else 0 */
 int32_t nm_ppo_has_fast_path(const nm_ppo* h);
 /* rsl_rl v1.0.2 PPO.act (caller reference train.py:54) in ONE launch, fast-path networks only: merged actor+critic forward from the

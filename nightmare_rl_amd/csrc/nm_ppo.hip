@@ -59,6 +59,7 @@ struct PpoBatch {
   int B, n_obs;
   float clip, vcoef, inv_B;
   int clip_value;
+  const int* rows;             // null: the mini-batch is rows 0..B-1 of the arrays; else row i of the mini-batch is row rows[i] (gather in the kernel)
 };
 
 __device__ __forceinline__ int pos(int c) { return (c & 3) * kQS + (c >> 2); }
@@ -93,9 +94,10 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const int rr = 2 * wave + h, row = row0 + rr;
+        const size_t srow = row < bt.B ? (bt.rows ? (size_t)bt.rows[row] : (size_t)row) : 0;
         for (int kk = lane; kk < Kp; kk += 64) {
           float v = 0.0f;
-          if (row < bt.B) v = kk < K ? bt.obs[(size_t)row * bt.n_obs + kk] : (kk == K ? 1.0f : 0.0f);
+          if (row < bt.B) v = kk < K ? bt.obs[srow * bt.n_obs + kk] : (kk == K ? 1.0f : 0.0f);
           act[0][rr * kLD + pos(kk)] = v;
         }
       }
@@ -131,11 +133,12 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
     if (wave == 0) {
       const int row = row0 + r, A = net.A;
       const bool live = row < bt.B;
+      const size_t srow = live ? (bt.rows ? (size_t)bt.rows[row] : (size_t)row) : 0;
       float lp = 0.0f, kl = 0.0f;
       for (int j = q; j < A; j += 4) {
         if (live) {
           const float mu = outb[r * kLD + pos(j)], sd = bt.std[j];
-          const float a = bt.actions[(size_t)row * A + j], omu = bt.old_mu[(size_t)row * A + j], osd = bt.old_sigma[(size_t)row * A + j];
+          const float a = bt.actions[srow * A + j], omu = bt.old_mu[srow * A + j], osd = bt.old_sigma[srow * A + j];
           const float z = (a - mu) / sd;
           lp += -0.5f * z * z - __logf(sd) - 0.9189385332046727f;
           kl += __logf(sd / osd + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) / (2.0f * sd * sd) - 0.5f;
@@ -145,7 +148,7 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
       kl += __shfl_xor(kl, 16); kl += __shfl_xor(kl, 32);
       float dlogp = 0.0f;      // d(surrogate)/d(logp) * (1/B)
       if (live) {
-        const float adv = bt.adv[row], ratio = __expf(lp - bt.old_logp[row]);
+        const float adv = bt.adv[srow], ratio = __expf(lp - bt.old_logp[srow]);
         const float s1 = -adv * ratio, rc = fminf(fmaxf(ratio, 1.0f - bt.clip), 1.0f + bt.clip), s2 = -adv * rc;
         const bool inside = ratio > 1.0f - bt.clip && ratio < 1.0f + bt.clip;
         // torch.max(s1, s2).backward(): the larger branch gets the gradient, a tie (ratio inside the clip range) splits it between
@@ -155,7 +158,7 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
         if (q == 0) {
           a_surr += fmaxf(s1, s2);
           a_kl += kl;
-          const float v = outb[r * kLD + pos(A)], R = bt.ret[row], tv = bt.tval[row];
+          const float v = outb[r * kLD + pos(A)], R = bt.ret[srow], tv = bt.tval[srow];
           float dv, vl;
           if (bt.clip_value) {
             const float dvt = v - tv, vc = tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
@@ -181,7 +184,7 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
         if (c < net.Op[net.n_layers - 1]) {
           float d = 0.0f, ds = 0.0f;
           if (live && c < A) {
-            const float mu = outb[r * kLD + pos(c)], sd = bt.std[c], a = bt.actions[(size_t)row * A + c];
+            const float mu = outb[r * kLD + pos(c)], sd = bt.std[c], a = bt.actions[srow * A + c];
             d = dlogp * (a - mu) / (sd * sd);
             ds = dlogp * ((a - mu) * (a - mu) / (sd * sd * sd) - 1.0f / sd);
           } else if (live && c == A) {
@@ -383,7 +386,7 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
   struct RowData { f32x4 obs[T0], act[PO], omu[PO], osd[PO]; float adv, olp, ret, tv; };
   auto load_rows = [&](int pass, RowData& rd) {
     const int row = (pass * kFastWaves + w) * 16 + r;
-    const size_t lrow = row < bt.B ? row : 0;
+    const size_t lrow = row < bt.B ? (bt.rows ? (size_t)bt.rows[row] : (size_t)row) : 0;
     sfor<T0>([&](auto T) {
       constexpr int t = T;
       if constexpr (16 * t + 16 <= I) {
@@ -920,6 +923,128 @@ __global__ void k_ppo_adam(float* __restrict__ flat, float* __restrict__ m, floa
   flat[i] = p;
   if (map[i] >= 0) Wm_all[map[i]] = p;
 }
+
+// The step of a mini-batch - k_ppo_reduce, k_ppo_scalars, k_ppo_adam and the repacking of k_ppo_pack - as ONE launch:
+// block b owns parameters 64 b .. 64 b + 63 from the sum of the partial gradients to the Adam update and writes the new value straight
+// into its places of the two MFMA packings (index tables built by nm_ppo_create). The only thing a block needs from the others is the
+// gradient norm: every block publishes the sum of squares of its 64 gradients (device-scope atomic), one grid barrier, then every block
+// adds the nblk partial sums in the same fixed order - so all blocks (and, after an all-reduce, all ranks) get the same clip coefficient
+// bit for bit - and evaluates the KL-adaptive learning rate itself from the workgroups' scalar tails; block 0 files the state.
+// nblk (~236) blocks of 512 threads are co-resident on the 256 CUs, which the spinning barrier needs; the spin is bounded (state[8] = 1
+// on a time-out: nm_ppo_get_state reports it).
+struct StepArgs {
+  const float* partial; int nwg, stride, gtotal;
+  const int* map; int n;
+  float *flat, *m, *v, *grad, *state, *Wm, *n2part;
+  float *pf, *pb; const int *pfi, *pbi;        // packings as float arrays + per-parameter positions in them (-1: none)
+  unsigned* bar;                                // [0] arrivals, [1] generation
+  float ent_coef, inv_B, desired_kl, max_norm, kl_override, b1, b2, eps;
+  int adaptive, kl_from_grad, do_reduce;
+};
+__global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a) {
+  __shared__ float part[kRedWaves][kRedParams];
+  const int lane = threadIdx.x & 63, w0 = threadIdx.x >> 6, b = blockIdx.x;
+  const int i = b * kRedParams + lane, n = a.n;
+  const float lr0 = a.state[0], t0 = a.state[1], s3 = a.state[3], s4 = a.state[4], s5 = a.state[5];   // read before the barrier: block 0 rewrites them behind it
+  const unsigned gen = __hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  float g = 0.0f;
+  int mp = 0;
+  if (i <= n) mp = i < n ? a.map[i] : -33;
+  if (a.do_reduce) {       // k_ppo_reduce's arithmetic and summation order
+    if (i <= n) {
+      const float* P = a.partial + (mp >= 0 ? mp : a.gtotal + (-mp - 1));
+      float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
+      int w = w0;
+      for (; w + 3 * kRedWaves < a.nwg; w += 4 * kRedWaves) {
+        g0 += P[(size_t)w * a.stride]; g1 += P[(size_t)(w + kRedWaves) * a.stride];
+        g2 += P[(size_t)(w + 2 * kRedWaves) * a.stride]; g3 += P[(size_t)(w + 3 * kRedWaves) * a.stride];
+      }
+      for (; w < a.nwg; w += kRedWaves) g0 += P[(size_t)w * a.stride];
+      g = (g0 + g1) + (g2 + g3);
+    }
+    part[w0][lane] = g;
+    __syncthreads();
+    if (w0 == 0 && i <= n) {
+      g = 0.0f;
+#pragma unroll
+      for (int w = 0; w < kRedWaves; w++) g += part[w][lane];
+      if (i == n) g *= a.inv_B;
+      else if (mp < 0) g -= a.ent_coef / a.flat[i];
+      a.grad[i] = g;
+    }
+  } else if (w0 == 0 && i <= n) {
+    g = a.grad[i];           // the caller's (all-reduced) gradient | KL
+  }
+  if (w0 == 0) {
+    float s = i < n ? g * g : 0.0f;
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) __hip_atomic_store(a.n2part + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  // ---- grid barrier (one per launch): the last block to arrive re-arms the counter and opens the next generation
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = atomicAdd(a.bar, 1u);
+    if (old == gridDim.x - 1) {
+      __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      int spins = 0;
+      while (__hip_atomic_load(a.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+        __builtin_amdgcn_s_sleep(4);
+        if (++spins > (1 << 22)) { a.state[8] = 1.0f; break; }     // never on an idle GPU; a hung barrier must not hang the device
+      }
+    }
+  }
+  __syncthreads();
+  if (w0 != 0) return;
+  // ---- the scalars of k_ppo_scalars, by every block in the same order
+  float n2 = 0.0f, kl = 0.0f, su = 0.0f, vl = 0.0f;
+  for (int j = lane; j < (int)gridDim.x; j += 64) n2 += __hip_atomic_load(a.n2part + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  for (int w = lane; w < a.nwg; w += 64) {
+    const float* P = a.partial + (size_t)w * a.stride + a.gtotal;
+    kl += P[32]; su += P[33]; vl += P[34];
+  }
+  for (int o = 32; o > 0; o >>= 1) { n2 += __shfl_xor(n2, o); kl += __shfl_xor(kl, o); su += __shfl_xor(su, o); vl += __shfl_xor(vl, o); }
+  float klm = kl * a.inv_B;
+  if (a.kl_from_grad) klm = a.grad[n];
+  if (a.kl_override >= 0.0f) klm = a.kl_override;
+  float lr = lr0;
+  if (a.adaptive) {                                    // rsl_rl v1.0.2 PPO.update: schedule == 'adaptive'
+    if (klm > a.desired_kl * 2.0f) lr = fmaxf(1e-5f, lr / 1.5f);
+    else if (klm < a.desired_kl / 2.0f && klm > 0.0f) lr = fminf(1e-2f, lr * 1.5f);
+  }
+  const float norm = sqrtf(n2), clipc = fminf(1.0f, a.max_norm / (norm + 1e-6f)), t = t0 + 1.0f;
+  if (b == 0 && lane == 0) {
+    a.state[0] = lr; a.state[1] = t; a.state[2] = klm; a.state[3] = s3 + vl * a.inv_B; a.state[4] = s4 + su * a.inv_B; a.state[5] = s5 + 1.0f;
+    a.state[6] = clipc; a.state[7] = norm;
+  }
+  if (i < n) {     // k_ppo_adam + this parameter's two packed copies
+    const float gc = g * clipc;
+    const float mi = a.b1 * a.m[i] + (1.0f - a.b1) * gc, vi = a.b2 * a.v[i] + (1.0f - a.b2) * gc * gc;
+    a.m[i] = mi; a.v[i] = vi;
+    const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);
+    const float p = a.flat[i] - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + a.eps);      // torch.optim.Adam (no amsgrad, no weight decay)
+    a.flat[i] = p;
+    if (mp >= 0) { a.Wm[mp] = p; a.pf[a.pfi[i]] = p; a.pb[a.pbi[i]] = p; }
+  }
+}
+
+// A random permutation of 0..n-1 without a sort (rsl_rl draws torch.randperm per update: storage/rollout_storage.py mini_batch_generator):
+// a 4-round Feistel network on the next even power of two, cycle-walked back into [0, n) - a bijection for every key. out[i] = image of i.
+__device__ __forceinline__ uint32_t perm_mix(uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
+__global__ void k_ppo_perm(int* __restrict__ out, int n, int half, uint32_t k0, uint32_t k1, uint32_t k2, uint32_t k3) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t mask = (1u << half) - 1u, key[4] = {k0, k1, k2, k3};
+  uint32_t x = (uint32_t)i;
+  do {
+    uint32_t L = x >> half, R = x & mask;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { const uint32_t F = perm_mix(R * 0x9E3779B1u + key[r]) & mask; const uint32_t nr = L ^ F; L = R; R = nr; }
+    x = (L << half) | R;
+  } while (x >= (uint32_t)n);
+  out[i] = (int)x;
+}
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------ handle + C ABI
@@ -932,6 +1057,10 @@ struct nm_ppo {
   float* Wm = nullptr;         // merged matrices, all layers
   f32x4 *pf = nullptr, *pb = nullptr;
   float *partial = nullptr, *grad = nullptr, *state = nullptr;
+  int *pfi = nullptr, *pbi = nullptr;       // per flat parameter: its float position in pf / pb (k_ppo_step writes the packings itself)
+  float* n2part = nullptr;
+  unsigned* bar = nullptr;
+  bool fused_step = true;                   // NM_PPO_UNFUSED_STEP=1: the four launches (reduce, scalars, adam, pack) - A/B timing and tests
   std::vector<size_t> pf_off, pb_off;
 };
 
@@ -948,7 +1077,8 @@ extern "C" int nm_ppo_destroy(nm_ppo* h) {
   if (!h) return 0;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  for (void* p : {(void*)h->map, (void*)h->Wm, (void*)h->pf, (void*)h->pb, (void*)h->partial, (void*)h->grad, (void*)h->state})
+  for (void* p : {(void*)h->map, (void*)h->Wm, (void*)h->pf, (void*)h->pb, (void*)h->partial, (void*)h->grad, (void*)h->state, (void*)h->pfi, (void*)h->pbi, (void*)h->n2part,
+                  (void*)h->bar})
     if (p) (void)hipFree(p);
   delete h;
   return 0;
@@ -1041,11 +1171,34 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
   bool ok = hipMalloc((void**)&h->map, map.size() * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->Wm, (size_t)h->wm_total * sizeof(float)) == hipSuccess &&
             hipMalloc((void**)&h->pf, pft * sizeof(f32x4)) == hipSuccess && hipMalloc((void**)&h->pb, pbt * sizeof(f32x4)) == hipSuccess &&
             hipMalloc((void**)&h->partial, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)) == hipSuccess &&
-            hipMalloc((void**)&h->grad, (map.size() + 1) * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->state, 8 * sizeof(float)) == hipSuccess;
+            hipMalloc((void**)&h->grad, (map.size() + 1) * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->state, 12 * sizeof(float)) == hipSuccess &&
+            hipMalloc((void**)&h->pfi, map.size() * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->pbi, map.size() * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&h->n2part, ((map.size() + 1 + kRedParams - 1) / kRedParams) * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->bar, 2 * sizeof(unsigned)) == hipSuccess;
   if (!ok) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: hipMalloc failed"); }
   PPO_CHK_H(hipMemcpy(h->map, map.data(), map.size() * sizeof(int), hipMemcpyHostToDevice));
   PPO_CHK_H(hipMemset(h->Wm, 0, (size_t)h->wm_total * sizeof(float)));
-  PPO_CHK_H(hipMemset(h->state, 0, 8 * sizeof(float)));
+  PPO_CHK_H(hipMemset(h->state, 0, 12 * sizeof(float)));
+  PPO_CHK_H(hipMemset(h->bar, 0, 2 * sizeof(unsigned)));
+  {   // where parameter i sits in the forward / backward packing (the layouts of k_ppo_pack), as float offsets into pf / pb
+    std::vector<int> pfi(map.size(), -1), pbi(map.size(), -1);
+    for (size_t i = 0; i < map.size(); i++) {
+      const int m = map[i];
+      if (m < 0) continue;
+      int l = 0;
+      while (l + 1 < n_layers && m >= n.goff[l + 1]) l++;
+      const int o = (m - n.goff[l]) / n.Kp[l], k = (m - n.goff[l]) % n.Kp[l];
+      int t, g, q, j, r;
+      if (h->fast) { t = o / 16; r = o % 16; g = k / 16; q = (k % 16) / 4; j = k % 4; }
+      else { t = o / 16; r = o % 16; g = k / 16; j = (k % 16) / 4; q = k % 4; }
+      pfi[i] = (int)((h->pf_off[l] + ((size_t)t * (n.Kp[l] / 16) + g) * 64 + q * 16 + r) * 4 + j);
+      if (h->fast) { t = k / 16; r = k % 16; g = o / 16; q = (o % 16) / 4; j = o % 4; }
+      else { t = k / 16; r = k % 16; g = o / 16; j = (o % 16) / 4; q = o % 4; }
+      pbi[i] = (int)((h->pb_off[l] + ((size_t)t * (n.Op[l] / 16) + g) * 64 + q * 16 + r) * 4 + j);
+    }
+    PPO_CHK_H(hipMemcpy(h->pfi, pfi.data(), pfi.size() * sizeof(int), hipMemcpyHostToDevice));
+    PPO_CHK_H(hipMemcpy(h->pbi, pbi.data(), pbi.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  h->fused_step = !(std::getenv("NM_PPO_UNFUSED_STEP") && std::atoi(std::getenv("NM_PPO_UNFUSED_STEP")) != 0);
   PPO_CHK_H(hipMemset(h->partial, 0, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)));
 #undef PPO_CHK_H
   for (int l = 0; l < n_layers; l++) { n.pf[l] = h->pf + h->pf_off[l]; n.pb[l] = h->pb + h->pb_off[l]; }
@@ -1066,16 +1219,29 @@ extern "C" int nm_ppo_sync_params(nm_ppo* h, const float* flat_dev, float lr, in
   PPO_CHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_ppo_scatter, dim3((h->nparam + 255) / 256), dim3(256), 0, s, flat_dev, h->map, h->nparam, h->Wm);
-  const float st[8] = {lr, (float)step, 0, 0, 0, 0, 1.0f, 0};
+  const float st[12] = {lr, (float)step, 0, 0, 0, 0, 1.0f, 0, 0, 0, 0, 0};
   PPO_CHK(hipMemcpyAsync(h->state, st, sizeof st, hipMemcpyHostToDevice, s));
   PPO_CHK(hipStreamSynchronize(s));      // st lives on this stack frame
   return ppo_pack(h, s);
 }
 // one mini-batch of PPO.update: forward, losses, backward, (optional: stop after the gradient for a multi-GPU all-reduce), clip, lr, Adam
+extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
+                                     const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* tval,
+                                     const int32_t* rows_dev, int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
+                                     int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
 extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
                                 const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* tval,
                                 int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
                                 int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream) {
+  return nm_ppo_minibatch_rows(h, flat_dev, exp_avg_dev, exp_avg_sq_dev, obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, nullptr, B, n_obs, clip, value_coef,
+                               entropy_coef, clip_value, desired_kl, adaptive, max_grad_norm, beta1, beta2, eps, phase, kl_override, stream);
+}
+// the same with the mini-batch given as row numbers into the (unpermuted) arrays: row i of the mini-batch is row rows_dev[i] - the gather
+// of rsl_rl's mini_batch_generator (obs[batch_idx], ...) happens inside the forward / backward kernel. rows_dev == NULL: rows 0..B-1.
+extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
+                                     const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* tval,
+                                     const int32_t* rows_dev, int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
+                                     int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream) {
   if (!h || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || !obs || !actions || !old_mu || !old_sigma || !old_logp || !adv || !ret || !tval || B <= 0)
     return nm_policy_set_error("nm_ppo_minibatch: bad argument");
   if (n_obs != h->net.Kr[0]) return nm_policy_set_error("nm_ppo_minibatch: observation width does not match the network");
@@ -1083,15 +1249,24 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
   hipStream_t s = (hipStream_t)stream;
   const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + 1 + kRedParams - 1) / kRedParams;
   if (phase == 0 || phase == 1) {     // 1: gradient only
-    PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value};
+    PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value, rows_dev};
     const int rows = h->fast ? 16 * kFastWaves : kRows;
     const int ntiles = (B + rows - 1) / rows, grid = ntiles < h->nwg ? ntiles : h->nwg;
     if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
     if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_fast<RefShape>, dim3(grid), dim3(64 * kFastWaves), 0, s, h->net, bt, h->partial);
     else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
-    hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
+    if (phase == 1 || !h->fused_step)
+      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
   }
-  if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced gradient | KL; the KL is then read from there
+  if ((phase == 0 || phase == 2) && h->fused_step) {     // reduce (phase 0) + scalars + Adam + both packings: one launch
+    StepArgs a;
+    a.partial = h->partial; a.nwg = h->nwg; a.stride = stride; a.gtotal = h->net.gtotal; a.map = h->map; a.n = h->nparam;
+    a.flat = flat_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev; a.grad = h->grad; a.state = h->state; a.Wm = h->Wm; a.n2part = h->n2part;
+    a.pf = reinterpret_cast<float*>(h->pf); a.pb = reinterpret_cast<float*>(h->pb); a.pfi = h->pfi; a.pbi = h->pbi; a.bar = h->bar;
+    a.ent_coef = entropy_coef; a.inv_B = 1.0f / (float)B; a.desired_kl = desired_kl; a.max_norm = max_grad_norm; a.kl_override = kl_override;
+    a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adaptive = adaptive; a.kl_from_grad = phase == 2 ? 1 : 0; a.do_reduce = phase == 0 ? 1 : 0;
+    hipLaunchKernelGGL(k_ppo_step, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, a);
+  } else if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced gradient | KL; the KL is then read from there
     hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nwg, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,
                        adaptive, max_grad_norm, kl_override, phase == 2 ? 1 : 0, h->state);
     hipLaunchKernelGGL(k_ppo_adam, dim3(nb), dim3(256), 0, s, flat_dev, exp_avg_dev, exp_avg_sq_dev, h->grad, h->nparam, h->state, beta1, beta2, eps, h->map, h->Wm);
@@ -1140,14 +1315,33 @@ extern "C" int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, v
   PPO_CHK(hipMemcpyAsync(direction ? h->grad : grad_dev, direction ? grad_dev : h->grad, ((size_t)h->nparam + 1) * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
+// out_dev[i] = image of i under a random permutation of 0..n-1 keyed by (seed, counter): the mini-batch order of one PPO.update
+// (rsl_rl v1.0.2 storage/rollout_storage.py mini_batch_generator: torch.randperm) without a sort or any library kernel
+extern "C" int nm_ppo_permutation(int32_t* out_dev, int32_t n, uint64_t seed, uint64_t counter, void* stream) {
+  if (!out_dev || n <= 0) return nm_policy_set_error("nm_ppo_permutation: bad argument");
+  int bits = 2;
+  while ((1ll << bits) < (long long)n) bits += 2;          // an even number of bits: two equal halves
+  uint32_t key[4];
+  uint64_t x = seed * 0x9E3779B97F4A7C15ull + counter * 0xD1B54A32D192ED03ull + 0x2545F4914F6CDD1Dull;
+  for (int r = 0; r < 4; r++) { x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31; key[r] = (uint32_t)(x >> 16); x += 0x9E3779B97F4A7C15ull; }
+  hipLaunchKernelGGL(k_ppo_perm, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, out_dev, n, bits / 2, key[0], key[1], key[2], key[3]);
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_permutation: launch failed");
+  return 0;
+}
 // HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, gradient norm.
 // reset_sums != 0 clears the loss sums and the mini-batch count afterwards. Synchronises the stream.
 extern "C" int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream) {
   if (!h || !out8_host) return nm_policy_set_error("nm_ppo_get_state: bad argument");
   PPO_CHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
-  PPO_CHK(hipMemcpyAsync(out8_host, h->state, 8 * sizeof(float), hipMemcpyDeviceToHost, s));
+  float st[9];
+  PPO_CHK(hipMemcpyAsync(st, h->state, 9 * sizeof(float), hipMemcpyDeviceToHost, s));
   PPO_CHK(hipStreamSynchronize(s));
+  for (int i = 0; i < 8; i++) out8_host[i] = st[i];
   if (reset_sums) PPO_CHK(hipMemsetAsync(h->state + 3, 0, 3 * sizeof(float), s));
+  if (st[8] != 0.0f) {      // k_ppo_step's grid barrier gave up waiting (its blocks were not co-resident): the step it took is not trustworthy
+    PPO_CHK(hipMemsetAsync(h->state + 8, 0, sizeof(float), s));
+    return nm_policy_set_error("nm_ppo: the grid barrier of the fused mini-batch step timed out (GPU shared with another job?); set NM_PPO_UNFUSED_STEP=1");
+  }
   return 0;
 }

@@ -217,18 +217,23 @@ class FusedUpdate:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._L.nm_ppo_sync_params(self._h, self.flat.data_ptr(), float(lr), int(self.step_count), stream))
 
-    def minibatch(self, obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hp, phase=0, kl_override=-1.0):
+    def minibatch(self, obs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, hp, phase=0, kl_override=-1.0, rows=None):
+        """rows: int32 device tensor of row numbers - the mini-batch is obs[rows], actions[rows], ... gathered INSIDE the kernel
+        (nm_ppo_minibatch_rows); None: the tensors are the mini-batch."""
         f = lambda t: t if (t.dtype == torch.float32 and t.is_contiguous()) else t.contiguous().float()
         obs, actions, old_mu, old_sigma = f(obs), f(actions), f(old_mu), f(old_sigma)
         old_logp, advantages, returns, target_values = f(old_logp), f(advantages), f(returns), f(target_values)
         b1, b2 = self.opt.param_groups[0]["betas"]
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        _lib.check(self._L.nm_ppo_minibatch(self._h, self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), obs.data_ptr(), actions.data_ptr(),
-                                            old_mu.data_ptr(), old_sigma.data_ptr(), old_logp.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
-                                            target_values.data_ptr(), obs.shape[0], obs.shape[1], hp["clip"], hp["value_coef"], hp["entropy_coef"],
-                                            int(hp["clip_value"]), hp["desired_kl"], int(hp["adaptive"]), hp["max_grad_norm"], b1, b2,
-                                            self.opt.param_groups[0]["eps"], phase, kl_override, stream))
-        self._keep = (obs, actions, old_mu, old_sigma, old_logp, advantages, returns, target_values)
+        if rows is not None and (rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != self.flat.device):
+            raise ValueError("minibatch: rows must be a contiguous int32 tensor on the update's device")
+        B = obs.shape[0] if rows is None else int(rows.numel())
+        _lib.check(self._L.nm_ppo_minibatch_rows(self._h, self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), obs.data_ptr(), actions.data_ptr(),
+                                                 old_mu.data_ptr(), old_sigma.data_ptr(), old_logp.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
+                                                 target_values.data_ptr(), None if rows is None else rows.data_ptr(), B, obs.shape[1], hp["clip"], hp["value_coef"],
+                                                 hp["entropy_coef"], int(hp["clip_value"]), hp["desired_kl"], int(hp["adaptive"]), hp["max_grad_norm"], b1, b2,
+                                                 self.opt.param_groups[0]["eps"], phase, kl_override, stream))
+        self._keep = (obs, actions, old_mu, old_sigma, old_logp, advantages, returns, target_values, rows)
         if phase != 1:
             self.step_count += 1
 
@@ -248,18 +253,25 @@ class FusedUpdate:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self._L.nm_ppo_copy_grad(self._h, g.data_ptr(), 1, stream))
 
-    def minibatch_data_parallel(self, *batch, hp, world):
+    def permutation(self, n, seed, counter, out=None):
+        """int32 [n]: a pseudo-random permutation of 0..n-1 keyed by (seed, counter), made on the device in one launch (nm_ppo_permutation)."""
+        out = torch.empty(int(n), dtype=torch.int32, device=self.device) if out is None else out
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_permutation(out.data_ptr(), int(n), int(seed) & 0xFFFFFFFFFFFFFFFF, int(counter), stream))
+        return out
+
+    def minibatch_data_parallel(self, *batch, hp, world, rows=None):
         """One mini-batch of a data-parallel update: local gradient, ONE all-reduce of gradient | KL (RCCL when the process group is
         nccl; every rank then applies the identical step), the step."""
         import torch.distributed as dist
-        self.minibatch(*batch, hp, phase=1)
+        self.minibatch(*batch, hp, phase=1, rows=rows)
         if getattr(self, "_gbuf", None) is None:
             self._gbuf = torch.empty(self.flat.numel() + 1, device=self.device)
         self.grad_and_kl(self._gbuf)
         dist.all_reduce(self._gbuf)
         self._gbuf.div_(world)
         self.set_grad_and_kl(self._gbuf)
-        self.minibatch(*batch, hp, phase=2)
+        self.minibatch(*batch, hp, phase=2, rows=rows)
 
     def read_state(self, reset_sums=True):
         """dict(lr, steps, kl, value_loss_sum, surrogate_loss_sum, minibatches, clip_coef, grad_norm); one stream synchronisation."""

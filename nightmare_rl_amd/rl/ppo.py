@@ -47,6 +47,7 @@ class PPO:
             self.fused.defer_record = True     # one launch per collection step (nm_ppo_record_act); end_rollout() files the last step
 
     resume_lr_from_checkpoint = False     # runner cfg flag of the same name (not in rsl_rl): see after_load
+    device_permutation = True             # fused update: mini-batch order from nm_ppo_permutation + in-kernel row gather (False: torch.randperm + gathered copies)
 
     def after_load(self):
         """Parameters / optimizer state were replaced from a checkpoint: let the kernels' copies follow. Like rsl_rl v1.0.2, `learning_rate`
@@ -145,13 +146,32 @@ class PPO:
                   desired_kl=self.desired_kl if self.desired_kl is not None else 0.0,
                   adaptive=self.desired_kl is not None and self.schedule == "adaptive", max_grad_norm=self.max_grad_norm)
         fu = self.fused_update
-        for (obs, _cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in \
-                self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
-            batch = (obs, actions, target_values.reshape(-1), advantages.reshape(-1), returns.reshape(-1), old_logp.reshape(-1), old_mu, old_sigma)
-            if _world() > 1:
-                fu.minibatch_data_parallel(*batch, hp=hp, world=_world())
-            else:
-                fu.minibatch(*batch, hp)
+        if self.device_permutation and self.storage.privileged_observations is None:
+            # rsl_rl's mini_batch_generator (indices = randperm; obs[batch_idx] ... per mini-batch) without the permuted copies of the rollout:
+            # the permutation comes from one small kernel, and the forward / backward kernel gathers its rows through it
+            st = self.storage
+            B = st.num_envs * st.num_transitions_per_env
+            mb = B // self.num_mini_batches
+            self._update_count = getattr(self, "_update_count", 0) + 1
+            rank = dist.get_rank() if _world() > 1 else 0
+            self._perm = fu.permutation(self.num_mini_batches * mb, torch.initial_seed() + 104729 * rank, self._update_count, out=getattr(self, "_perm", None))
+            flat = (st.observations.flatten(0, 1), st.actions.flatten(0, 1), st.values.reshape(-1), st.advantages.reshape(-1), st.returns.reshape(-1),
+                    st.actions_log_prob.reshape(-1), st.mu.flatten(0, 1), st.sigma.flatten(0, 1))
+            for _ in range(self.num_learning_epochs):
+                for i in range(self.num_mini_batches):
+                    rows = self._perm[i * mb:(i + 1) * mb]
+                    if _world() > 1:
+                        fu.minibatch_data_parallel(*flat, hp=hp, world=_world(), rows=rows)
+                    else:
+                        fu.minibatch(*flat, hp, rows=rows)
+        else:
+            for (obs, _cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in \
+                    self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
+                batch = (obs, actions, target_values.reshape(-1), advantages.reshape(-1), returns.reshape(-1), old_logp.reshape(-1), old_mu, old_sigma)
+                if _world() > 1:
+                    fu.minibatch_data_parallel(*batch, hp=hp, world=_world())
+                else:
+                    fu.minibatch(*batch, hp)
         st = fu.read_state()                      # the one host synchronisation of the update
         self.learning_rate, self.last_kl = st["lr"], st["kl"]
         for g in self.optimizer.param_groups:

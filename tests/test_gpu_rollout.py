@@ -196,3 +196,77 @@ def test_runner_trains_through_the_one_launch_rollout(tmp_path):
     ta, tb = np.median([h["collection_time"] for h in a[3:]]), np.median([h["collection_time"] for h in b[3:]])
     print(f"collection per iteration: one launch {ta * 1e3:.2f} ms, captured per-step graph {tb * 1e3:.2f} ms")
     assert ta < tb
+
+
+# ------------------------------------------------------------------------------------------------ the update side of the same round
+def test_device_permutation_is_a_bijection_and_mixes():
+    """nm_ppo_permutation (rsl_rl: torch.randperm in mini_batch_generator): for sizes around powers of two and the real one (4096 envs x 80
+    steps) the image of 0..n-1 is 0..n-1; different (seed, counter) give different orders; no structure a mini-batch would inherit
+    (the first quarter of the permuted order covers all 80 steps and all envs about evenly)."""
+    from nightmare_rl_amd.rl.fused import FusedUpdate
+    ac, fu = _networks()
+    for n in (1, 2, 3, 17, 255, 256, 257, 4095, 4096, 4097, 100000, 4096 * 80):
+        p = fu.permutation(n, seed=12345, counter=7)
+        assert p.dtype == torch.int32 and p.numel() == n
+        assert torch.equal(torch.sort(p.long()).values, torch.arange(n, device=DEV)), n
+    n = 4096 * 80
+    p0, p1, p2 = fu.permutation(n, 1, 1), fu.permutation(n, 1, 2), fu.permutation(n, 2, 1)
+    assert float((p0 == p1).float().mean()) < 1e-3 and float((p0 == p2).float().mean()) < 1e-3
+    assert torch.equal(p0, fu.permutation(n, 1, 1))
+    q = p0[: n // 4].long()
+    steps, envs = torch.bincount(q // 4096, minlength=80).float(), torch.bincount(q % 4096, minlength=4096).float()
+    assert steps.min() > 0.85 * steps.mean() and steps.max() < 1.15 * steps.mean()            # ~1024 per step, sd 28
+    assert envs.min() >= 5 and envs.max() <= 45                                               # ~20 per env, sd 3.9
+    # consecutive indices do not land next to each other
+    d = (p0[1:].long() - p0[:-1].long()).abs().float()
+    assert float((d < 64).float().mean()) < 0.002
+
+
+@pytest.mark.parametrize("shape", ["reference-fast", "reference-generic"])
+def test_row_gather_inside_the_kernel_equals_the_gathered_copy_and_the_fused_step_equals_four_launches(shape, monkeypatch):
+    """(a) nm_ppo_minibatch_rows on the unpermuted rollout + row numbers == nm_ppo_minibatch on torch-gathered copies: parameters and Adam
+    moments bit for bit after 3 steps. (b) the one-launch step (reduce + norm + learning rate + Adam + packing behind one grid barrier) ==
+    the four launches (NM_PPO_UNFUSED_STEP=1): same learning rate decisions, parameters to rounding of the gradient-norm sum, and the
+    packed weights the next forward reads are the new parameters (the second and third step would diverge otherwise)."""
+    import copy
+    from nightmare_rl_amd.rl import ActorCritic
+    from nightmare_rl_amd.rl.fused import FusedUpdate
+    if shape == "reference-generic":
+        monkeypatch.setenv("NM_PPO_GENERIC", "1")
+    torch.manual_seed(2)
+    mk = lambda: ActorCritic(66, 66, 18, actor_hidden_dims=[54, 42, 30], critic_hidden_dims=[54, 42, 30], activation="elu", init_noise_std=0.8).to(DEV)
+    ac = mk()
+    acs = [ac, copy.deepcopy(ac), copy.deepcopy(ac)]
+    fus = []
+    for k, a in enumerate(acs):
+        if k == 2:
+            monkeypatch.setenv("NM_PPO_UNFUSED_STEP", "1")
+        fus.append(FusedUpdate(a, torch.optim.Adam(a.parameters(), lr=1e-3), DEV, lr=1e-3))
+    monkeypatch.delenv("NM_PPO_UNFUSED_STEP")
+    hp = dict(clip=0.2, value_coef=1.0, entropy_coef=0.0015, clip_value=True, desired_kl=0.01, adaptive=True, max_grad_norm=1.0)
+    R = 4096 * 6 + 5
+    gen = torch.Generator(device=DEV).manual_seed(8)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    obs = rn(R, 66)
+    with torch.no_grad():
+        old_mu = acs[0].actor(obs) + 0.05 * rn(R, 18)
+        old_sigma = (acs[0].std * (1 + 0.05 * rn(18))).expand(R, 18).contiguous()
+        actions = old_mu + old_sigma * rn(R, 18)
+        old_logp = torch.distributions.Normal(old_mu, old_sigma).log_prob(actions).sum(-1)
+        tv = acs[0].critic(obs).squeeze(-1) + 0.3 * rn(R)
+    adv, ret = rn(R), tv + rn(R)
+    full = (obs, actions, tv, adv, ret, old_logp, old_mu, old_sigma)
+    perm = fus[0].permutation(R, 5, 1)
+    B = 4096 * 2 + 3
+    for step in range(3):
+        rows = perm[step * B:(step + 1) * B]
+        fus[0].minibatch(*full, hp, rows=rows)
+        gathered = tuple(t[rows.long()] for t in full)
+        fus[1].minibatch(*gathered, hp)
+        fus[2].minibatch(*gathered, hp)
+        s0, s1, s2 = (f.read_state() for f in fus)
+        assert torch.equal(fus[0].flat, fus[1].flat) and torch.equal(fus[0].m, fus[1].m) and torch.equal(fus[0].v, fus[1].v), step
+        assert s0 == s1
+        assert s1["lr"] == s2["lr"] and abs(s1["grad_norm"] - s2["grad_norm"]) < 2e-6 * s2["grad_norm"] and abs(s1["kl"] - s2["kl"]) < 1e-6 * s2["kl"] + 1e-9
+        torch.testing.assert_close(fus[1].flat, fus[2].flat, atol=1e-7, rtol=2e-6)
+        torch.testing.assert_close(fus[1].m, fus[2].m, atol=1e-9, rtol=2e-6)
