@@ -230,6 +230,19 @@ def main():
             valu = tj.get("valu")
         except Exception:
             pmc_file = None
+        # secondary roofline: fp32 operations the kernel actually executes (rocprofv3 --pmc pass committed under profiles/, the same
+        # way as `traffic`) over THIS run's kernel time, against the 157.3 TFLOP/s fp32 vector peak of MI355X_MICROARCH.md
+        valu_fp32 = None
+        lf = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_lanes.json")))
+        if lf:
+            try:
+                lj = json.load(open(lf[-1]))
+                flop = lj["fp32_flop_per_launch"] * (E / float(lj["envs"]))
+                valu_fp32 = {"bound": "valu-f32", "achieved": flop / k_avg / 1e12, "peak": 157.3, "unit": "TFLOP/s", "frac": flop / k_avg / 1e12 / 157.3,
+                             "fp32_flop_per_launch": flop, "active_lanes_per_valu_instruction": lj["active_lanes_per_valu_instruction"],
+                             "source": os.path.relpath(lf[-1], ROOT) + " (counters not measured in this run; kernel time is)"}
+            except Exception:
+                valu_fp32 = None
         # physics-only (BASELINE config 2) and step + 2x256 MLP policy forward (config 3), for DESIGN.md / the log
         torch.cuda.synchronize(dev)
         t1 = time.perf_counter()
@@ -262,6 +275,33 @@ def main():
             graph.replay()
         torch.cuda.synchronize(dev)
         closed = E * 10 * per_graph / (time.perf_counter() - t1)
+        # the collection loop of the PPO runner (reference train.py:54: act -> step -> process_env_step, 80 steps, the reference's 66-54-42-30-18|1
+        # networks) as ONE launch with the policy inside the env's wave (nm_rollout): policy + step + transition record per env-step
+        roll = None
+        try:
+            from nightmare_rl_amd.rl import ActorCritic, RolloutStorage
+            from nightmare_rl_amd.rl.fused import FusedCollector, FusedUpdate
+            torch.manual_seed(0)
+            ac = ActorCritic(66, 66, 18, actor_hidden_dims=[54, 42, 30], critic_hidden_dims=[54, 42, 30], activation="elu", init_noise_std=1.0).to(dev)
+            fu = FusedUpdate(ac, torch.optim.Adam(ac.parameters(), lr=1e-3), dev, lr=1e-3)
+            col = FusedCollector(ac, E, dev, seed=1, update=fu)
+            if col.can_rollout(env):
+                T = horizon
+                st = RolloutStorage(E, T, [66], [None], [18], dev)
+                zz = lambda *sh: torch.zeros(*sh, device=dev)
+                cr, cl, fin = zz(E), zz(E), zz(3)
+                eidx = torch.tensor([env._stat_names.index(k[4:]) for k in sorted(env.extras["episode"])], dtype=torch.int32, device=dev)
+                eacc = zz(eidx.numel())
+                for i in range(2):
+                    col.rollout(env, st, T, 0.99, cr, cl, fin, ep=(eidx, eacc))
+                torch.cuda.synchronize(dev)
+                t1 = time.perf_counter()
+                for i in range(5):
+                    col.rollout(env, st, T, 0.99, cr, cl, fin, ep=(eidx, eacc))
+                torch.cuda.synchronize(dev)
+                roll = E * T * 5 / (time.perf_counter() - t1)
+        except Exception as exc:       # a secondary figure: never fails the headline
+            roll = f"failed: {type(exc).__name__}: {exc}"
         # the fp64 verification build of the same kernel (what the exact-parity tests run)
         cfg64 = NightmareV3Config()
         cfg64.env.num_envs = E
@@ -292,10 +332,11 @@ def main():
                          "kernel": "k_env_step<float,2>", "kernel_avg_us": k_avg * 1e6, "kernel_launches_timed": n_leg,
                          "kernel_avg_us_event_pair_per_launch": k_avg_pairs * 1e6,
                          "algorithmic_bytes_per_env_step": B_FULL,
-                         "valu": valu,
+                         "valu": valu, "valu_fp32": valu_fp32,
                          "note": "latency/VALU-issue bound, not HBM bound: see DESIGN.md"},
             "physics_only_env_steps_per_s": phys,
             "closed_loop_mlp_2x256_env_steps_per_s": closed,
+            "policy_rollout_one_launch_env_steps_per_s": roll,
             "fp64_verification_kernel_env_steps_per_s": f64,
             "counters": env.counters(),
         }

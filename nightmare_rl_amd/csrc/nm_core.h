@@ -1315,6 +1315,32 @@ template <int C, int N, class F> NM_FN void for_contacts(int ncon, F&& f) {
     }
   }
 }
+// ---- The two update rules of the constraint solver, stated ONCE. The three row layouts below (row per lane on 64 lanes, two envs on
+// half-waves, matrix-free rows in three slots per lane) differ in how a row's delta reaches the other rows' residuals - a v_readlane
+// broadcast into a register-resident A row, two of them under the halves' masks, a block-factor solve through LDS - not in these
+// formulas; a change to either rule is made here and nowhere else.
+// mj_solPGS (engine_solver.c), one row of a pyramidal contact: residual res = (A f + b)_i + R_i f_i with the CURRENT forces, projected
+// coordinate step f_i <- max(f_i - res / (A_ii + R_i), 0); returns the delta, leaves the residual in `res` (the row's cost change needs it)
+template <class X> NM_FN X pgs_row_delta(const X& g, const X& Rr, const X& f, const X& ARinv, X& res) {
+  res = g + Rr * f;
+  return vmax(-res * ARinv, -f);              // = max(f - res/AR_ii, 0) - f
+}
+// ... and its cost change 0.5 dl^2 AR_ii + dl res (hA = 0.5 AR_ii): what mj_solPGS sums for the tolerance exit
+template <class X> NM_FN X pgs_row_cost(const X& dl, const X& hA, const X& res) { return dl * (hA * dl + res); }
+// mj_solNoSlip (engine_solver.c), one opposing pyramid pair seen from ONE of its two rows (f, g = own force and residual without R; fp, gp =
+// the partner's): exact 1-D minimisation along (f - fp) - a Newton step on the difference of the two residuals (K1 = A00 + A11 - 2 A01,
+// invK1 = 1 / K1, hK1 = 0.5 K1), clamped so that both forces stay non-negative (their sum is kept); a degenerate pair (K1 < 1e-15) goes to
+// its mean. `change` = the pair's cost change d (0.5 K1 d + dg), `bad` = mj_solNoSlip's revert test (change > 1e-10): the caller drops d then.
+template <class real, class X, class B> NM_FN X noslip_pair_delta(const X& g, const X& gp, const X& f, const X& fp, const X& invK1, const X& hK1, const B& small,
+                                                                    X& change, B& bad) {
+  const X dg = g - gp;
+  X d = vmin(vmax(-dg * invK1, -f), fp);
+  d = sel(small, real(0.5) * (fp - f), d);
+  change = d * (hK1 * d + dg);
+  bad = change > X(real(1e-10));     // costChange: revert an update that does not decrease the cost
+  return d;
+}
+
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
 template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep) {
   typedef V<real> vr;
@@ -1582,8 +1608,8 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int i = 4 * cc + r;
-        vr res = g + Rr * f;
-        vr dl = vmax(-res * ARinv, -f);              // = max(f - res/AR_ii, 0) - f
+        vr res;
+        vr dl = pgs_row_delta(g, Rr, f, ARinv, res);
         g += A[i] * rdlane(dl, i);
         VB me = lv == i;
         dcap = sel(me, dl, dcap);
@@ -1594,7 +1620,7 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     // whose cost change exceeds +1e-10; for this projected coordinate step that cannot happen: unclamped, 0.5 AR dl + res =
     // res (1 - 0.5 AR/AR~) has the sign of res = -sign(dl); clamped at zero, res >= AR f makes it -f (res - 0.5 AR f) <= 0 - no
     // cancellation in either case, so no test.
-    const vr ccap = dcap * (hA * dcap + rcap);
+    const vr ccap = pgs_row_cost(dcap, hA, rcap);
     f = f + dcap;
     sh.it_pgs = iter + 1;
     if (-wsum<real>(ccap) * M.pgs_scale < M.pgs_tol) break;
@@ -1637,11 +1663,9 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       for (int p = 0; p < kMaxRow / 2; p++) {
         if ((p & 1) == 0 && !(p / 2 < ncon)) break;   // one uniform test per contact (two pairs)
         {
-          const vr oq = shfl_xor1(f), dg = g - shfl_xor1(g);
-          vr d = vmin(vmax(-dg * invK1, -f), oq);
-          d = sel(small, real(0.5) * (oq - f), d);
-          const vr change = d * (hK1 * d + dg);
-          const VB bad = change > vr(real(1e-10));     // costChange: revert an update that does not decrease the cost
+          vr change;
+          VB bad;
+          vr d = noslip_pair_delta<real>(g, shfl_xor1(g), f, shfl_xor1(f), invK1, hK1, small, change, bad);
           d = sel(bad, vr(real(0)), d);
           g += A[2 * p] * rdlane(d, 2 * p);
           const VB me = lvp == p;
@@ -1950,15 +1974,16 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int i = 4 * cc + r;
-          vr res = g + Rr * f;
-          vr dl = sel(run, vmax(-res * ARinv, -f), vr(real(0)));
+          vr res;
+          vr dl = pgs_row_delta(g, Rr, f, ARinv, res);
+          dl = sel(run, dl, vr(real(0)));
           g += A[i] * RDL(dl, i);
           VB me = lv == i;
           dcap = sel(me, dl, dcap);
           rcap = sel(me, res, rcap);       // the residual this row saw at its own step: its cost change is formed once, after the sweep
         }
       });
-      const vr ccap = dcap * (hA * dcap + rcap);
+      const vr ccap = pgs_row_cost(dcap, hA, rcap);
       f = f + dcap;
       itp = itp + sel(run, V<int>(1), V<int>(0));
       run = run & !((-hsum32(ccap)) * M.pgs_scale < vr(M.pgs_tol));
@@ -1995,11 +2020,9 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
       for (int p = 0; p < kMaxRow2 / 2; p++) {
         if ((p & 1) == 0 && !(p / 2 < nmax)) break;   // one uniform test per contact (two pairs)
         {
-          const vr oq = shfl_xor1(f), dg = g - shfl_xor1(g);
-          vr d = vmin(vmax(-dg * invK1, -f), oq);
-          d = sel(small, real(0.5) * (oq - f), d);
-          const vr change = d * (hK1 * d + dg);
-          const VB bad = change > vr(real(1e-10));
+          vr change;
+          VB bad;
+          vr d = noslip_pair_delta<real>(g, shfl_xor1(g), f, shfl_xor1(f), invK1, hK1, small, change, bad);
           d = sel(bad | !run, vr(real(0)), d);
           g += A[2 * p] * RDL(d, 2 * p);
           const VB me = lvp == p;
@@ -2344,9 +2367,9 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
     for (int k = 0; k < kBigSlots; k++) {
       for (int ln = 0; ln < NM_WAVE; ln++) {
         if (NM_WAVE * k + ln >= nefc) break;
-        const vr res = big_residual(sh, r, k) + r.Rr[k] * r.f[k];
-        const vr dl = vmax(-res * r.ARinv[k], -r.f[k]);
-        const vr change = dl * (r.hA[k] * dl + res);
+        vr res;
+        const vr dl = pgs_row_delta(big_residual(sh, r, k), r.Rr[k], r.f[k], r.ARinv[k], res);
+        const vr change = pgs_row_cost(dl, r.hA[k], res);
         const real d = rdlane(dl, ln);
         improvement -= rdlane(change, ln);
         r.f[k] = sel(lane == ln, r.f[k] + dl, r.f[k]);
@@ -2375,11 +2398,9 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
       for (int pp = 0; pp < NM_WAVE / 2; pp++) {
         if (NM_WAVE * k + 2 * pp >= nefc) break;
         const vr g = big_residual(sh, r, k);
-        const vr oq = shfl_xor1(r.f[k]), dg = g - shfl_xor1(g);
-        vr d = vmin(vmax(-dg * r.invK1[k], -r.f[k]), oq);
-        d = sel(r.small[k], real(0.5) * (oq - r.f[k]), d);
-        const vr change = d * (r.hK1[k] * d + dg);
-        const VB bad = change > vr(real(1e-10));
+        vr change;
+        VB bad;
+        vr d = noslip_pair_delta<real>(g, shfl_xor1(g), r.f[k], shfl_xor1(r.f[k]), r.invK1[k], r.hK1[k], r.small[k], change, bad);
         d = sel(bad, vr(real(0)), d);
         const real d0 = rdlane(d, 2 * pp), d1 = rdlane(d, 2 * pp + 1);
         improvement -= rdlane(sel(bad, vr(real(0)), change), 2 * pp);

@@ -841,7 +841,7 @@ __global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restr
 }
 // gradient of every real parameter: sum of the workgroups' partial gradients at its merged position (std: from the scalar tail,
 // plus the entropy bonus -c_e * d(sum_j log std_j)/d(std_j))
-constexpr int kRedParams = 64, kRedWaves = 8;
+constexpr int kRedParams = 64, kRedWaves = 16;   // 16 waves x 4 independent load chains per block: the sum over the 256 partial gradients is a latency chain (8 waves: 20 us)
 __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
                              const float* __restrict__ flat, float ent_coef, float inv_B, float* __restrict__ grad) {
   // entry n (one past the parameters) = this mini-batch's mean KL to the behaviour policy: it travels with the gradient through a
@@ -978,7 +978,10 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a)
   if (w0 == 0) {
     float s = i < n ? g * g : 0.0f;
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-    if (lane == 0) __hip_atomic_store(a.n2part + b, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // published by a RETURNING device-scope atomic whose value this lane consumes: it has been performed at the coherence point before the
+    // block's arrival below is issued - no release fence (on this chip that is an L2 write-back: the first version of this kernel, with
+    // release / acquire on the barrier flag, took 110 us instead of 20)
+    if (lane == 0) { const float was = atomicExch(a.n2part + b, s); asm volatile("" ::"v"(was) : "memory"); }
   }
   // ---- grid barrier (one per launch): the last block to arrive re-arms the counter and opens the next generation
   __syncthreads();
@@ -986,10 +989,10 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a)
     const unsigned old = atomicAdd(a.bar, 1u);
     if (old == gridDim.x - 1) {
       __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
       int spins = 0;
-      while (__hip_atomic_load(a.bar + 1, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+      while (__hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
         __builtin_amdgcn_s_sleep(4);
         if (++spins > (1 << 22)) { a.state[8] = 1.0f; break; }     // never on an idle GPU; a hung barrier must not hang the device
       }

@@ -231,6 +231,7 @@ struct RollArgs {
   float *cur_ret, *cur_len, *fin3;                             // the runner's episode bookkeeping (nm_ppo_record's)
   float* st_sum; int* st_cnt;                                  // [K,kNREW], [K,4]: per-step accumulators (Args::stat_sum / stat_cnt of that step)
   int* to_step;                                                // [N]: the step at which the env timed out in this rollout, or -1
+  unsigned long long* wave_clock;                              // measurement (nm_set_debug_buffer on): [waves][2] s_memtime at the wave's start / end, else null
 };
 struct TailArgs {
   int N, K;

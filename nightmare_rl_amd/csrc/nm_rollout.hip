@@ -87,11 +87,13 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_rollout(const nm:
   if ((int)threadIdx.x < 2 && wave * 2 + (int)threadIdx.x < A.N) R.to_step[wave * 2 + threadIdx.x] = -1;
   const uint64_t noise0 = A.noise_step;
   const int K = R.K;
+  if (R.wave_clock && threadIdx.x == 0) R.wave_clock[2 * wave] = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < K; t++) {
     policy_step<S>(xb, &Rs, &As, t, wave, noise0);
     nm::wave_step<float, 2>(sh, Ms, As, wave);        // env.step: load, decimation x mj_step, epilogue - the code of k_env_step
     record_step(&Rs, &As, t, wave);
   }
+  if (Rs.wave_clock && threadIdx.x == 0) Rs.wave_clock[2 * wave + 1] = __builtin_amdgcn_s_memtime();
 }
 // One env's policy step as a launch of its own: PPO.act on the same wave code (the step-by-step counterpart of k_env_rollout and its
 // bit-exact reference in tests/test_gpu_rollout.py). One wave = two envs.

@@ -185,7 +185,24 @@ class FusedUpdate:
         cdims = (C.c_int32 * (len(c) + 1))(c[0].in_features, *[m.out_features for m in c])
         h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        _lib.check(self._L.nm_ppo_create(adims, cdims, len(a), idx, C.byref(h)))
+        # The one-launch mini-batch step (k_ppo_step) synchronises its ~236 workgroups with a spinning grid barrier: they must all be
+        # resident at once, i.e. the GPU must not be shared with another process's kernels. One rank per GPU (RCCL requires it) is fine;
+        # the shared-card rehearsal of the multi-rank path over gloo is not - there the four-launch step is used (nm_ppo_create reads the
+        # switch). A barrier that does time out makes nm_ppo_get_state fail loudly.
+        import os
+        import torch.distributed as dist
+        shared = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1 and dist.get_backend() != "nccl"
+        prev = os.environ.get("NM_PPO_UNFUSED_STEP")
+        if shared:
+            os.environ["NM_PPO_UNFUSED_STEP"] = "1"
+        try:
+            _lib.check(self._L.nm_ppo_create(adims, cdims, len(a), idx, C.byref(h)))
+        finally:
+            if shared:
+                if prev is None:
+                    os.environ.pop("NM_PPO_UNFUSED_STEP", None)
+                else:
+                    os.environ["NM_PPO_UNFUSED_STEP"] = prev
         self._h = h
         assert self._L.nm_ppo_num_params(h) == n
         self.A, self.n_obs = a[-1].out_features, a[0].in_features

@@ -47,6 +47,7 @@ class PPO:
             self.fused.defer_record = True     # one launch per collection step (nm_ppo_record_act); end_rollout() files the last step
 
     resume_lr_from_checkpoint = False     # runner cfg flag of the same name (not in rsl_rl): see after_load
+    update_graph = True                   # fused update on one GPU: replay the mini-batch launches of an update as one HIP graph
     device_permutation = True             # fused update: mini-batch order from nm_ppo_permutation + in-kernel row gather (False: torch.randperm + gathered copies)
 
     def after_load(self):
@@ -157,13 +158,44 @@ class PPO:
             self._perm = fu.permutation(self.num_mini_batches * mb, torch.initial_seed() + 104729 * rank, self._update_count, out=getattr(self, "_perm", None))
             flat = (st.observations.flatten(0, 1), st.actions.flatten(0, 1), st.values.reshape(-1), st.advantages.reshape(-1), st.returns.reshape(-1),
                     st.actions_log_prob.reshape(-1), st.mu.flatten(0, 1), st.sigma.flatten(0, 1))
-            for _ in range(self.num_learning_epochs):
-                for i in range(self.num_mini_batches):
-                    rows = self._perm[i * mb:(i + 1) * mb]
-                    if _world() > 1:
-                        fu.minibatch_data_parallel(*flat, hp=hp, world=_world(), rows=rows)
-                    else:
-                        fu.minibatch(*flat, hp, rows=rows)
+
+            def epochs():
+                for _ in range(self.num_learning_epochs):
+                    for i in range(self.num_mini_batches):
+                        rows = self._perm[i * mb:(i + 1) * mb]
+                        if _world() > 1:
+                            fu.minibatch_data_parallel(*flat, hp=hp, world=_world(), rows=rows)
+                        else:
+                            fu.minibatch(*flat, hp, rows=rows)
+
+            # All mini-batches of an update read and write fixed addresses (storage rows, the permutation buffer, the flat parameter and
+            # moment vectors; learning rate, KL and Adam's step count live on the device): from the third update on, the 2 x epochs x
+            # mini-batches launches are ONE HIP graph replay. The permutation above is redrawn every update outside the graph.
+            key = (tuple(t.data_ptr() for t in flat), self._perm.data_ptr(), mb, tuple(sorted(hp.items())))
+            if self.update_graph and _world() == 1 and torch.device(self.device).type == "cuda":
+                if getattr(self, "_upd_graph", None) is not None and self._upd_graph[0] == key:
+                    self._upd_graph[1].replay()
+                    fu.step_count += self.num_learning_epochs * self.num_mini_batches
+                elif self._update_count >= 3 and getattr(self, "_upd_graph", None) != "failed":
+                    try:
+                        torch.cuda.synchronize()
+                        g = torch.cuda.CUDAGraph()
+                        # under inference_mode like the runner's rollout capture: torch keeps per-generator capture tensors, and whichever
+                        # capture of the process comes first decides whether they are inference tensors - in-place updates of those are
+                        # allowed in here in both cases, outside only in one
+                        with torch.inference_mode(), torch.cuda.graph(g):
+                            epochs()
+                        self._upd_graph = (key, g)
+                        g.replay()             # the capture executed nothing
+                    except Exception as exc:
+                        import warnings
+                        warnings.warn(f"PPO update graph capture failed ({type(exc).__name__}: {exc}); staying on per-launch updates")
+                        self._upd_graph = "failed"
+                        epochs()
+                else:
+                    epochs()
+            else:
+                epochs()
         else:
             for (obs, _cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in \
                     self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):

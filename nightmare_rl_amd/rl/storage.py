@@ -66,9 +66,10 @@ class RolloutStorage:
                 delta = self.rewards[s] + live * gamma * nxt - self.values[s]
                 adv = delta + live * gamma * lam * adv
                 self.returns[s] = adv + self.values[s]
-        self.advantages = self.returns - self.values
+        # in place: the update's captured graph (rl/ppo.py) reads the advantages at a fixed address
+        torch.sub(self.returns, self.values, out=self.advantages)
         mean, std = global_advantage_stats(self.advantages)   # over ALL ranks' envs x steps
-        self.advantages = (self.advantages - mean) / (std + 1e-8)
+        self.advantages.sub_(mean).div_(std + 1e-8)
 
     def get_statistics(self):
         done = self.dones.clone()

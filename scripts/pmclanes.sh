@@ -45,6 +45,19 @@ if 0 in res and 1 in res and 4 in res and 13 in res:
     stage(1, 13, "smooth dynamics (mask 1 - mask 13)")
     a = res[13]
     print(f"   stage {'load + 2 x integrate + epilogue (mask 13)':44s}: {a['SQ_INSTS_VALU'] / a.get('SQ_WAVES', 2048):7.0f} VALU/wave, active lanes {a['SQ_THREAD_CYCLES_VALU'] / max(a['SQ_ACTIVE_INST_VALU'], 1):5.1f}")
+import json
+if 0 in res:
+    a = res[0]
+    lanes = a["SQ_THREAD_CYCLES_VALU"] / max(a["SQ_ACTIVE_INST_VALU"], 1)
+    fl = (a["SQ_INSTS_VALU_ADD_F32"] + a["SQ_INSTS_VALU_MUL_F32"] + 2 * a["SQ_INSTS_VALU_FMA_F32"] + a["SQ_INSTS_VALU_TRANS_F32"]) * lanes
+    json.dump({"source": "rocprofv3 --kernel-trace --pmc pass of scripts/pmcmask.py 0 (4096 envs, the 10 last launches), scripts/pmclanes.sh",
+               "kernel": "k_env_step<float,2>", "envs": 4096,
+               "active_lanes_per_valu_instruction": lanes, "valu_insts_per_wave": a["SQ_INSTS_VALU"] / a.get("SQ_WAVES", 2048),
+               "f32_wave_instructions_per_launch": {"add": a["SQ_INSTS_VALU_ADD_F32"], "mul": a["SQ_INSTS_VALU_MUL_F32"], "fma": a["SQ_INSTS_VALU_FMA_F32"], "trans": a["SQ_INSTS_VALU_TRANS_F32"]},
+               "fp32_flop_per_launch": fl,
+               "definition": "(add + mul + 2 fma + trans wave-instructions) x active lanes per VALU instruction (SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU); "
+                             "'active' = exec-mask lanes: the leg-lane stages run exact duplicates on lanes that hold no leg, which this counts as work"},
+              open(out + "/lanes.json", "w"), indent=1)
 k = avg_of("k0")
 if k:
     w = k.get("SQ_WAVES", 2048)
