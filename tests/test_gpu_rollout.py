@@ -270,3 +270,27 @@ def test_row_gather_inside_the_kernel_equals_the_gathered_copy_and_the_fused_ste
         assert s1["lr"] == s2["lr"] and abs(s1["grad_norm"] - s2["grad_norm"]) < 2e-6 * s2["grad_norm"] and abs(s1["kl"] - s2["kl"]) < 1e-6 * s2["kl"] + 1e-9
         torch.testing.assert_close(fus[1].flat, fus[2].flat, atol=1e-7, rtol=2e-6)
         torch.testing.assert_close(fus[1].m, fus[2].m, atol=1e-9, rtol=2e-6)
+
+
+def test_learning_curve_at_4096_envs_lies_inside_the_cpu_reference_band():
+    """BASELINE config 5's 'return curve vs CPU ref' as an assertion: the runner on the HIP env (fp32 kernels, one-launch rollout, fused
+    update) for 25 iterations at 4096 envs against the band the SAME runner reached on the CPU oracle env (fp64, torch PPO; 3 seeds,
+    tests/golden/curve_cpu_band_4096.json, made by tests/tools/curve_vs_cpu.py). The two sides differ in env precision, PPO kernels and
+    noise generators, so the comparison is statistical: inside the CPU seeds' [min, max] widened by its own width on either side."""
+    import json
+    import os
+    from nightmare_rl_amd.envs.helpers import class_to_dict
+    from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3ConfigPPO
+    from nightmare_rl_amd.rl import OnPolicyRunner
+    band = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "curve_cpu_band_4096.json")))["band"]
+    torch.manual_seed(100)
+    env = make_env(4096, seed=100)
+    r = OnPolicyRunner(env, class_to_dict(NightmareV3ConfigPPO()), log_dir=None, device=DEV)
+    r.learn(25, init_at_random_ep_len=True)
+    assert r.rollout_mode.startswith("one launch")
+    for m in (10, 25):
+        b = band[str(m)]
+        v = float(np.mean([h["mean_step_reward"] for h in r.history[m - 5:m]]))
+        w = b["max"] - b["min"]
+        assert b["min"] - w <= v <= b["max"] + w, (m, v, b)
+    env.close()
