@@ -841,7 +841,7 @@ __global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restr
 }
 // gradient of every real parameter: sum of the workgroups' partial gradients at its merged position (std: from the scalar tail,
 // plus the entropy bonus -c_e * d(sum_j log std_j)/d(std_j))
-constexpr int kRedParams = 64, kRedWaves = 16;   // 16 waves x 4 independent load chains per block: the sum over the 256 partial gradients is a latency chain (8 waves: 20 us)
+constexpr int kRedParams = 64, kRedWaves = 8;    // (16 waves per block measured no faster: 31.0 vs 29.8 us for k_ppo_step)
 __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
                              const float* __restrict__ flat, float ent_coef, float inv_B, float* __restrict__ grad) {
   // entry n (one past the parameters) = this mini-batch's mean KL to the behaviour policy: it travels with the gradient through a

@@ -11,7 +11,10 @@ if [ "$PART" != "b" ]; then
 echo "== bench"; python bench.py > $OUT/${TAG}_bench.json.log 2>&1; tail -c 600 $OUT/${TAG}_bench.json.log; echo
 echo "== train 40 iterations + play"; rm -rf logs; python train.py -e 4096 --iters 40 > $OUT/${TAG}_train40.log 2>&1; grep -E "^it +(1|20|39)/" $OUT/${TAG}_train40.log
 python scripts/play.py --log-root logs/nightmare_v3 -e 64 --steps 400 > $OUT/${TAG}_play.log 2>&1; tail -4 $OUT/${TAG}_play.log
-echo "== curves (HIP side)"; python tests/tools/curve_vs_cpu.py --kinds hip --envs 256 --iters 150 --seeds 3 --merge profiles/r02_curve_cpu_runs.json --out $OUT/${TAG}_curve_vs_cpu.json > $OUT/${TAG}_curve.log 2>&1; grep -E "^it +[0-9]+  mean" $OUT/${TAG}_curve.log
+echo "== curves (HIP side; the CPU side of the same size: profiles/r04_curve_cpu_runs.json, tests/tools/curve_vs_cpu.py --kinds cpu in the build container)"
+python tests/tools/curve_vs_cpu.py --kinds hip --envs 4096 --iters 150 --seeds 3 --merge profiles/r04_curve_cpu_runs.json --out $OUT/${TAG}_curve_vs_cpu.json > $OUT/${TAG}_curve.log 2>&1; grep -E "^it +[0-9]+  mean" $OUT/${TAG}_curve.log
+echo "== one-launch rollout"; python scripts/rolloutbench.py 4096 80 > $OUT/${TAG}_rolloutbench.txt 2>&1; grep -v amdgpu $OUT/${TAG}_rolloutbench.txt
+python scripts/rolloutwaves.py 4096 80 > $OUT/${TAG}_rolloutwaves.txt 2>&1; grep -v amdgpu $OUT/${TAG}_rolloutwaves.txt
 cd /tmp && export TMPDIR=/tmp
 echo "== rocprof kernel stats: bench"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_bench -o run -- python3 $ROOT/bench.py --steps 200 --warmup 50 --no-cpu-baseline > $OUT/${TAG}_prof_bench.log 2>&1
 echo "== rocprof kernel stats: train"; rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_prof_train -o run -- python3 $ROOT/train.py -e 4096 --iters 12 > $OUT/${TAG}_prof_train.log 2>&1
@@ -27,5 +30,6 @@ echo "== wave lifetimes + stage stamps + parity report"
 python scripts/wavetimes.py > $OUT/${TAG}_wavetimes.txt 2>&1; tail -3 $OUT/${TAG}_wavetimes.txt
 [ -f nightmare_rl_amd/csrc/libnightmare_hip_stamps.so ] && NM_HIP_LIB=nightmare_rl_amd/csrc/libnightmare_hip_stamps.so python scripts/stamps.py > $OUT/${TAG}_stage_stamps.txt 2>&1
 python tests/tools/parity_report.py > $OUT/${TAG}_parity_report.txt 2>&1; tail -5 $OUT/${TAG}_parity_report.txt
+echo "== lane utilisation / fp32 operation counts per stage"; bash scripts/pmclanes.sh > $OUT/${TAG}_pmclanes_run.log 2>&1; cp $OUT/pmclanes/summary.txt $OUT/${TAG}_pmc_lanes_summary.txt; cp $OUT/pmclanes/lanes.json $OUT/${TAG}_pmc_lanes.json; cat $OUT/${TAG}_pmc_lanes_summary.txt
 fi
 echo done
