@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 for name in ("bench.json.log", "bench_kernel_stats.csv", "train_kernel_stats.csv", "mlp_kernel_stats.csv", "pmc_step_summary.txt", "pmc_mlp_summary.txt",
-             "curve_vs_cpu.json", "train40.log", "play.log", "parity_report.txt", "wavetimes.txt", "stage_stamps.txt"):
+             "curve_vs_cpu.json", "curve.log", "train40.log", "play.log", "parity_report.txt", "wavetimes.txt", "stage_stamps.txt", "rolloutbench.txt", "rolloutwaves.txt",
+             "pmc_lanes_summary.txt", "pmc_lanes.json", "bench_driverargs.json.log"):
     src = os.path.join(G, f"{tag}_{name}")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))
