@@ -128,7 +128,7 @@ __global__ void __launch_bounds__(64 * (sizeof(real) == 8 ? 1 : kWG), NM_WAVES_P
   // counter - at most 64 + 32 same-address atomics in a row instead of gridDim.x. A wave draws its group ticket as soon as everything
   // it contributes to the bookkeeping is published (inside the epilogue, before rewards and observation), so the round trip of that
   // atomic is off the critical path of the wave that finishes last.
-  const int nw = (int)gridDim.x * kWG, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
+  const int nw = (As.N + G - 1) / G, grp = wave / nm::kTicketGroup, ngrp = (nw + nm::kTicketGroup - 1) / nm::kTicketGroup;
   const int gsize = min(nm::kTicketGroup, nw - grp * nm::kTicketGroup);
   int ticket = 0, top = 0;
   int stage = 0;                       // 0: nothing drawn, 1: group ticket drawn, 2: group ticket resolved (and the top one drawn if this wave closes its group)
