@@ -181,3 +181,15 @@ def test_time_outs_refresh_is_incremental_on_its_own_buffer_and_full_on_any_othe
     _, _, _, done, extras = env.step(zero)
     if int(done.sum()) == 0:
         np.testing.assert_array_equal(extras["time_outs"].cpu().numpy(), want)
+    # a replacement that lands on the SAME ADDRESS (a caching allocator hands a freed block back) cannot be told from "the
+    # buffer I refreshed last" by the device - the env notices the new tensor object and invalidates (nm_invalidate_time_outs)
+    addr = env.time_out_buf.data_ptr()
+    same_place = env.time_out_buf.view(-1)                      # another tensor object on the same memory ...
+    same_place.fill_(7.0)                                       # ... with contents the incremental refresh would leave behind
+    env.time_out_buf = same_place
+    assert env.time_out_buf.data_ptr() == addr
+    ids4 = torch.tensor([11, 12])
+    done, to = step_with_timeouts(ids4)
+    want = np.zeros(N, np.float32); want[ids4.numpy()] = 1
+    np.testing.assert_array_equal(to, want)
+    assert env.extras["time_outs"] is env.time_out_buf

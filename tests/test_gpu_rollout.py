@@ -76,17 +76,17 @@ def _record(L, env, st, s, gamma, cur_ret, cur_len, fin, ep_idx, ep_acc):
                                env._ep_stats.data_ptr(), ep_idx.data_ptr(), int(ep_idx.numel()), ep_acc.data_ptr(), stream))
 
 
-@pytest.mark.parametrize("N,T", [(2048, 80), (63, 100)])
-def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T):
+@pytest.mark.parametrize("N,T,noise", [(2048, 80, False), (63, 100, False), (256, 40, True)])
+def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise):
     """nm_rollout(K = T) against T x [nm_rollout_act, nm_step, nm_ppo_record] from the same start (random episode lengths, so that time-outs,
-    falls and command resamples happen inside the rollout; N = 63: steps WITHOUT any reset occur, where extras['time_outs'] and
+    falls and command resamples happen inside the rollout; the third case with observation noise on; N = 63: steps WITHOUT any reset occur, where extras['time_outs'] and
     extras['episode'] are stale and rsl_rl's process_env_step / the runner's running sum use the stale values - and half a wave is empty).
     Two rollouts back to back, so that what the first one leaves behind (time-out flags, episode sums, counters) is what the second starts from."""
     from nightmare_rl_amd import _lib
     L = _lib.load()
     ac, fu = _networks()
     gamma = 0.99
-    envs = [make_env(N, seed=11), make_env(N, seed=11)]
+    envs = [make_env(N, seed=11, noise=noise), make_env(N, seed=11, noise=noise)]     # noise: cfg.noise.add_noise (env.py:304-305), keyed by the step count of the env
     for e in envs:
         e.reset()
         torch.manual_seed(3)
