@@ -134,6 +134,9 @@ __global__ void __launch_bounds__(64 * (sizeof(real) == 8 ? 1 : kWG), NM_WAVES_P
   int stage = 0;                       // 0: nothing drawn, 1: group ticket drawn, 2: group ticket resolved (and the top one drawn if this wave closes its group)
   bool closes_group = false;
   auto draw = [&](int phase) {
+#ifdef NM_NO_TICKETS   // measurement only (results without extras): what the end-of-step tickets cost
+    stage = 2; (void)phase; return;
+#endif
     if (phase == 0) {
       if (NM_TID == 0) ticket = atomicAdd(As.wave_done + (grp + 1) * nm::kTicketStride, 1);
       stage = 1;
