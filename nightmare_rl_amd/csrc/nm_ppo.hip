@@ -1,6 +1,6 @@
 // nm_ppo.hip - PPO mini-batch update of rsl_rl v1.0.2 (`algorithms/ppo.py` PPO.update; caller reference train.py:54) on hand-written
 // kernels: forward of actor and critic, the clipped-surrogate / clipped-value / entropy losses, the whole backward pass, gradient-norm
-// clipping, the KL-adaptive learning rate and Adam - four launches per mini-batch, no host synchronisation, instead of ~60 framework
+// clipping, the KL-adaptive learning rate and Adam - TWO launches per mini-batch (k_ppo_fwdbwd*, k_ppo_step), no host synchronisation, instead of ~60 framework
 // launches (elementwise chains on [81920 x 54] activations + library GEMMs with K = 82 k).
 //
 // The two MLPs (reference envs/nightmare_v3_config.py:107-109: 66 -> 54 -> 42 -> 30 -> 18 and -> 1, ELU) run as ONE merged network:
@@ -14,9 +14,10 @@
 //   walk (<= 16 tiles of 16x16 per wave) and are written once per workgroup as a partial gradient. The loss head (one wave) turns the
 //   network output into d(loss)/d(mean), d(loss)/d(value), and accumulates d(loss)/d(std), the KL to the behaviour policy and the
 //   loss values.
-// k_ppo_reduce : partial gradients -> gradient of every real parameter (merged-matrix position looked up in a table) + squared norm.
-// k_ppo_scalars: KL mean -> learning rate (rsl_rl's adaptive schedule), clip coefficient, loss statistics, std gradient.
-// k_ppo_adam   : Adam step on the flat parameter vector, then the two packed copies of the merged weights for the next mini-batch.
+// k_ppo_step   : the rest of a mini-batch in one launch with one grid barrier - partial gradients -> gradient of every real parameter,
+//   gradient norm -> clip coefficient, KL mean -> learning rate (rsl_rl's adaptive schedule), Adam, the two packed copies of the weights.
+// k_ppo_reduce / k_ppo_scalars / k_ppo_adam / k_ppo_pack: the same as four launches (data-parallel phase 1 uses k_ppo_reduce alone; the
+//   whole chain is the NM_PPO_UNFUSED_STEP=1 path for GPUs shared between processes).
 #include <hip/hip_runtime.h>
 
 #include <cmath>

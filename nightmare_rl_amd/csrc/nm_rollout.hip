@@ -20,15 +20,40 @@
 
 namespace nmr {
 
-// PPO.act of step t for the wave's envs + the launch arguments of the env step that follows. Out of line: its registers (weight ring,
-// accumulators) are not live across the physics, and the physics' are not live here.
+// PPO.process_env_step + the runner's bookkeeping for this wave's envs (k_ppo_record's arithmetic), in two halves so that its loads travel
+// with the next policy step's observation loads (one L2 round trip instead of two): `load` right after the step's stores have landed,
+// `file` whenever the values are needed. The time-out bootstrap needs the step's extras['time_outs'], a cross-wave quantity: k_rollout_tail adds it.
+struct RecordRegs { float rw, to, cr, cl; long long d; };
+__device__ __forceinline__ void record_load(RecordRegs& r, const RollArgs* Rs, const nm::Args<float>* As, int wave) {
+  const int lane = threadIdx.x, e = min(wave * 2 + (lane & 1), As->N - 1);
+  r.rw = As->rew[e]; r.d = As->done[e]; r.to = As->timeout_now[e]; r.cr = Rs->cur_ret[e]; r.cl = Rs->cur_len[e];
+}
+__device__ __forceinline__ void record_file(const RecordRegs& r, const RollArgs* Rs, const nm::Args<float>* As, int t, int wave) {
+  const int lane = threadIdx.x, N = As->N, e = wave * 2 + lane;
+  if (lane < 2 && e < N) {
+    const size_t so = (size_t)t * N;
+    const bool d = r.d > 0;
+    float cr = r.cr + r.rw, cl = r.cl + 1.0f;
+    Rs->s_rewards[so + e] = r.rw;
+    Rs->s_dones[so + e] = d ? 1 : 0;
+    if (d) { atomicAdd(Rs->fin3, cr); atomicAdd(Rs->fin3 + 1, cl); atomicAdd(Rs->fin3 + 2, 1.0f); cr = 0.f; cl = 0.f; }
+    Rs->cur_ret[e] = cr; Rs->cur_len[e] = cl;
+    if (r.to != 0.f) Rs->to_step[e] = t;
+  }
+}
+// The record of step t - 1 (t > 0) and PPO.act of step t for the wave's envs + the launch arguments of the env step that follows.
+// Out of line: its registers (weight ring, accumulators) are not live across the physics, and the physics' are not live here.
 template <class S>
 __device__ __noinline__ void policy_step(float* xb, const RollArgs* Rs, nm::Args<float>* As, int t, int wave, uint64_t noise0) {
   const int N = As->N;
   const size_t so = (size_t)t * N;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // state rows, observation, reward / done / time-out of the previous step: stored
+  RecordRegs rec;
+  if (t > 0) record_load(rec, Rs, As, wave);         // issued before the observation loads below: they return together
   ActOut o{Rs->s_actions + so * nm::kNU, Rs->s_logp + so, Rs->s_values + so, Rs->s_mu + so * nm::kNU, Rs->s_sigma + so * nm::kNU, t == 0 ? Rs->s_obs : nullptr};
-  // the observation is the one this wave's previous step wrote into the storage row of step t (its stores have been waited for)
+  // the observation is the one this wave's previous step wrote into the storage row of step t
   policy_wave<S>(xb, Rs->wp, Rs->bp, Rs->stdv, t == 0 ? Rs->obs0 : Rs->s_obs + so * nm::kNOBS, N, wave, Rs->seed, (uint64_t)Rs->iter_dev[0] * 4096ull + (uint64_t)t, o);
+  if (t > 0) record_file(rec, Rs, As, t - 1, wave);
   if (threadIdx.x == 0) {
     As->actions = o.actions;
     As->obs = t + 1 < Rs->K ? Rs->s_obs + (so + N) * nm::kNOBS : Rs->obs_final;     // the step files its observation where the next act reads it
@@ -39,23 +64,12 @@ __device__ __noinline__ void policy_step(float* xb, const RollArgs* Rs, nm::Args
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the actions are in L2 before the load stage asks for them (other lanes of this wave)
   nm::wave_sync();
 }
-// PPO.process_env_step + the runner's bookkeeping for this wave's envs (k_ppo_record's arithmetic). The time-out bootstrap needs the
-// step's extras['time_outs'], a cross-wave quantity: k_rollout_tail adds it.
-__device__ __noinline__ void record_step(const RollArgs* Rs, const nm::Args<float>* As, int t, int wave) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // state rows, observation, reward / done / time-out of this step: stored
-  const int lane = threadIdx.x, N = As->N, e = wave * 2 + lane;
-  if (lane < 2 && e < N) {
-    const size_t so = (size_t)t * N;
-    const float rw = As->rew[e];
-    const bool d = As->done[e] > 0;
-    const bool to = As->timeout_now[e] != 0.f;
-    float cr = Rs->cur_ret[e] + rw, cl = Rs->cur_len[e] + 1.0f;
-    Rs->s_rewards[so + e] = rw;
-    Rs->s_dones[so + e] = d ? 1 : 0;
-    if (d) { atomicAdd(Rs->fin3, cr); atomicAdd(Rs->fin3 + 1, cl); atomicAdd(Rs->fin3 + 2, 1.0f); cr = 0.f; cl = 0.f; }
-    Rs->cur_ret[e] = cr; Rs->cur_len[e] = cl;
-    if (to) Rs->to_step[e] = t;
-  }
+// the record of the rollout's last step (no policy step follows it)
+__device__ __noinline__ void record_last(const RollArgs* Rs, const nm::Args<float>* As, int t, int wave) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  RecordRegs rec;
+  record_load(rec, Rs, As, wave);
+  record_file(rec, Rs, As, t, wave);
 }
 
 template <class S>
@@ -89,10 +103,10 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_rollout(const nm:
   const int K = R.K;
   if (R.wave_clock && threadIdx.x == 0) R.wave_clock[2 * wave] = __builtin_amdgcn_s_memtime();
   for (int t = 0; t < K; t++) {
-    policy_step<S>(xb, &Rs, &As, t, wave, noise0);
+    policy_step<S>(xb, &Rs, &As, t, wave, noise0);    // (+ the record of step t - 1)
     nm::wave_step<float, 2>(sh, Ms, As, wave);        // env.step: load, decimation x mj_step, epilogue - the code of k_env_step
-    record_step(&Rs, &As, t, wave);
   }
+  record_last(&Rs, &As, K - 1, wave);
   if (Rs.wave_clock && threadIdx.x == 0) Rs.wave_clock[2 * wave + 1] = __builtin_amdgcn_s_memtime();
 }
 // One env's policy step as a launch of its own: PPO.act on the same wave code (the step-by-step counterpart of k_env_rollout and its
@@ -110,27 +124,37 @@ __global__ void __launch_bounds__(64) k_roll_act(const f32x4* __restrict__ wp, c
 //   * extras['time_outs'] likewise keeps the flags of the last step that had a reset, and PPO.process_env_step adds gamma * value *
 //     time_outs at EVERY step - so an env's bootstrap term is applied from its time-out step until the next step with a reset.
 //     `time_outs` on entry = the flags left by the steps before this rollout; on exit = those of the last refreshing step.
+constexpr int kTailSteps = 4096;     // nm_rollout's limit on K
 __global__ void __launch_bounds__(256) k_rollout_tail(TailArgs a) {
-  __shared__ float eps[nm::kNREW];
+  __shared__ int cnts[kTailSteps];      // resets of step t (> 0: the step refreshed the extras) - read K times by every thread below
   const int tid = threadIdx.x, N = a.N, K = a.K;
+  for (int t = tid; t < K; t += 256) cnts[t] = a.st_cnt[t * 4];
+  __syncthreads();
   if (blockIdx.x == 0) {
-    if (tid < nm::kNREW) eps[tid] = a.ep_stats ? a.ep_stats[tid] : 0.f;
-    __syncthreads();
-    long long c1 = 0, c2 = 0;
-    for (int t = 0; t < K; t++) {       // sequential in the step: K x a few dependent shared-memory operations
-      const int cnt = a.st_cnt[t * 4];
-      if (cnt > 0 && tid < nm::kNREW) eps[tid] = (float)(a.st_sum[(size_t)t * nm::kNREW + tid] / (float)cnt / a.ep_len_s);
-      __syncthreads();
-      if (tid < a.n_ep) a.ep_acc[tid] += eps[a.ep_idx[tid]];
-      __syncthreads();
-      c1 += a.st_cnt[t * 4 + 1]; c2 += a.st_cnt[t * 4 + 2];
+    // extras['episode'][k] after every step, and the runner's running sum of it: thread k < 16 follows reward k, thread 16 + i the i-th
+    // summed key - each walks the K steps on its own (no exchange: a summed key recomputes its reward's value), additions in step order
+    if (tid < nm::kNREW + a.n_ep) {
+      const bool sums = tid >= nm::kNREW;
+      const int k = sums ? a.ep_idx[tid - nm::kNREW] : tid;
+      float e = a.ep_stats ? a.ep_stats[k] : 0.f, acc = sums ? a.ep_acc[tid - nm::kNREW] : 0.f;
+      for (int t = 0; t < K; t++) {
+        const int cnt = cnts[t];
+        if (cnt > 0) e = (float)(a.st_sum[(size_t)t * nm::kNREW + k] / (float)cnt / a.ep_len_s);
+        acc += e;
+      }
+      if (sums) a.ep_acc[tid - nm::kNREW] = acc;
+      else if (a.ep_stats) a.ep_stats[k] = e;
     }
-    if (tid < nm::kNREW && a.ep_stats) a.ep_stats[tid] = eps[tid];
-    if (tid == 0) { a.counters[0] += c1; a.counters[1] += c2; *a.to_owner = 0ull; }   // the next nm_step rewrites extras['time_outs'] in full
+    if (tid == 255) {
+      long long c1 = 0, c2 = 0;
+      for (int t = 0; t < K; t++) { c1 += a.st_cnt[t * 4 + 1]; c2 += a.st_cnt[t * 4 + 2]; }
+      a.counters[0] += c1; a.counters[1] += c2;
+      *a.to_owner = 0ull;          // the next nm_step rewrites extras['time_outs'] in full
+    }
   }
   // time-out bootstrap and the final extras['time_outs'], one thread per env
   int tl = -1;
-  for (int t = 0; t < K; t++) if (a.st_cnt[t * 4] > 0) tl = t;
+  for (int t = 0; t < K; t++) if (cnts[t] > 0) tl = t;
   for (int e = blockIdx.x * blockDim.x + tid; e < N; e += gridDim.x * blockDim.x) {
     const int ts = a.to_step[e];
     // k_ppo_record's `rew + gamma * value * time_out` with time_out = 1: the product rounded, then the sum rounded (bit for bit)
@@ -141,9 +165,9 @@ __global__ void __launch_bounds__(256) k_rollout_tail(TailArgs a) {
       a.s_rewards[i] = a.s_rewards[i] + gv;
     };
     if (a.time_outs && a.time_outs[e] != 0.f)                  // flags from before the rollout hold until the first refresh
-      for (int t = 0; t < K && a.st_cnt[t * 4] == 0; t++) boot(t);
+      for (int t = 0; t < K && cnts[t] == 0; t++) boot(t);
     if (ts >= 0 && a.time_outs)
-      for (int t = ts; t < K && (t == ts || a.st_cnt[t * 4] == 0); t++) boot(t);
+      for (int t = ts; t < K && (t == ts || cnts[t] == 0); t++) boot(t);
     if (a.time_outs && tl >= 0) a.time_outs[e] = ts == tl ? 1.f : 0.f;
   }
 }
