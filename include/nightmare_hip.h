@@ -239,8 +239,10 @@ typedef struct {
   float* obs_final_dev;                /* [N,66] receives the observation after the last step (may alias obs0_dev) */
   int64_t* episode_length_dev;         /* [N] episode_length_buf, in/out */
   float* rew_dev; int64_t* done_dev;   /* [N] the env's reward / reset buffers: hold the last step's values afterwards */
-  float* time_outs_dev;                /* [N] extras['time_outs'] in/out (NULL: no time-out bootstrap), ep_stats_dev [NM_NUM_REWARDS] extras['episode'] in/out */
+  float* time_outs_dev;                /* [N] extras['time_outs'] in/out (NULL: not kept), ep_stats_dev [NM_NUM_REWARDS] extras['episode'] in/out */
   float* ep_stats_dev;
+  int32_t bootstrap_time_outs;         /* 1: rewards += gamma * value * extras['time_outs'] (what PPO.process_env_step does when the env sends time_outs,
+                                          cfg.env.send_timeouts, envs/nightmare_v3_env.py:369); 0: the buffer is kept up to date, the rewards stay raw */
   float *s_obs, *s_actions, *s_logp, *s_values, *s_mu, *s_sigma, *s_rewards;   /* rollout storage rows [K,N,66] [K,N,18] [K,N] [K,N] [K,N,18] [K,N,18] [K,N] */
   unsigned char* s_dones;              /* [K,N] */
   float gamma;                         /* time-out bootstrap: rewards += gamma * value * extras['time_outs'] (PPO.process_env_step) */

@@ -28,7 +28,7 @@ class NmConfig(C.Structure):
 class NmRolloutArgs(C.Structure):     # nm_rollout_args of include/nightmare_hip.h
     _fields_ = [("steps", C.c_int32), ("params_flat_dev", C.c_void_p), ("seed", C.c_uint64), ("iter_dev", C.c_void_p),
                 ("obs0_dev", C.c_void_p), ("obs_final_dev", C.c_void_p), ("episode_length_dev", C.c_void_p),
-                ("rew_dev", C.c_void_p), ("done_dev", C.c_void_p), ("time_outs_dev", C.c_void_p), ("ep_stats_dev", C.c_void_p),
+                ("rew_dev", C.c_void_p), ("done_dev", C.c_void_p), ("time_outs_dev", C.c_void_p), ("ep_stats_dev", C.c_void_p), ("bootstrap_time_outs", C.c_int32),
                 ("s_obs", C.c_void_p), ("s_actions", C.c_void_p), ("s_logp", C.c_void_p), ("s_values", C.c_void_p), ("s_mu", C.c_void_p),
                 ("s_sigma", C.c_void_p), ("s_rewards", C.c_void_p), ("s_dones", C.c_void_p), ("gamma", C.c_float),
                 ("cur_ret", C.c_void_p), ("cur_len", C.c_void_p), ("fin3", C.c_void_p),

@@ -582,7 +582,7 @@ template <class real> struct Env : nm_env {
       R.s_rewards = r->s_rewards; R.s_dones = r->s_dones; R.cur_ret = r->cur_ret; R.cur_len = r->cur_len; R.fin3 = r->fin3;
       R.st_sum = roll_sum; R.st_cnt = roll_cnt; R.to_step = roll_to;
       R.wave_clock = A.dbg ? reinterpret_cast<unsigned long long*>(A.dbg) : nullptr;   // measurement: the debug buffer ([N,256] reals) takes the waves' clocks instead
-      nmr::TailArgs ta{N, K, roll_sum, roll_cnt, roll_to, r->ep_stats_dev, r->time_outs_dev, M.ep_len_s, counters_dev, r->gamma, r->s_values, r->s_rewards,
+      nmr::TailArgs ta{N, K, roll_sum, roll_cnt, roll_to, r->ep_stats_dev, r->time_outs_dev, M.ep_len_s, counters_dev, r->bootstrap_time_outs ? r->gamma : -1.0f, r->s_values, r->s_rewards,
                        r->ep_idx_dev, r->n_ep, r->ep_acc_dev, A.to_owner};
       if (nmr::launch_rollout(M_dev, a, R, ta, s)) return fail("nm_rollout: launch failed");
       return 0;

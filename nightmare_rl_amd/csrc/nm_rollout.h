@@ -239,7 +239,7 @@ struct TailArgs {
   float *ep_stats, *time_outs;
   float ep_len_s;
   long long* counters;
-  float gamma;
+  float gamma;                 // < 0: no time-out bootstrap (the env does not send time_outs)
   const float* s_values; float* s_rewards;
   const int* ep_idx; int n_ep; float* ep_acc;
   unsigned long long* to_owner;

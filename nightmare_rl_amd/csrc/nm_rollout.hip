@@ -164,9 +164,10 @@ __global__ void __launch_bounds__(256) k_rollout_tail(TailArgs a) {
       const float gv = a.gamma * a.s_values[i];
       a.s_rewards[i] = a.s_rewards[i] + gv;
     };
-    if (a.time_outs && a.time_outs[e] != 0.f)                  // flags from before the rollout hold until the first refresh
+    const bool boots = a.gamma >= 0.f;
+    if (boots && a.time_outs && a.time_outs[e] != 0.f)         // flags from before the rollout hold until the first refresh
       for (int t = 0; t < K && cnts[t] == 0; t++) boot(t);
-    if (ts >= 0 && a.time_outs)
+    if (boots && ts >= 0 && a.time_outs)
       for (int t = ts; t < K && (t == ts || cnts[t] == 0); t++) boot(t);
     if (a.time_outs && tl >= 0) a.time_outs[e] = ts == tl ? 1.f : 0.f;
   }

@@ -239,7 +239,8 @@ class NightmareV3Env:
         a.obs_final_dev = self.obs_buf.data_ptr()
         a.episode_length_dev = self._eplen().data_ptr()
         a.rew_dev, a.done_dev = self.rew_buf.data_ptr(), self.reset_buf.data_ptr()
-        a.time_outs_dev = self.time_out_buf.data_ptr() if self.cfg.env.send_timeouts else None
+        a.time_outs_dev = self.time_out_buf.data_ptr()
+        a.bootstrap_time_outs = 1 if self.cfg.env.send_timeouts else 0
         a.ep_stats_dev = self._ep_stats.data_ptr()
         a.s_obs, a.s_actions, a.s_logp, a.s_values = (storage.observations.data_ptr(), storage.actions.data_ptr(), storage.actions_log_prob.data_ptr(),
                                                        storage.values.data_ptr())

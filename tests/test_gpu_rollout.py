@@ -71,13 +71,14 @@ def test_wave_policy_equals_torch_and_shares_the_noise_of_nm_ppo_act(N):
 def _record(L, env, st, s, gamma, cur_ret, cur_len, fin, ep_idx, ep_acc):
     from nightmare_rl_amd import _lib
     stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(L.nm_ppo_record(env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), env.time_out_buf.data_ptr(), st.values[s].data_ptr(), float(gamma), env.num_envs,
+    tout = env.extras["time_outs"].data_ptr() if "time_outs" in env.extras else None      # what rsl_rl's `if 'time_outs' in infos` sees
+    _lib.check(L.nm_ppo_record(env.rew_buf.data_ptr(), env.reset_buf.data_ptr(), tout, st.values[s].data_ptr(), float(gamma), env.num_envs,
                                st.rewards[s].data_ptr(), st.dones[s].data_ptr(), cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr(),
                                env._ep_stats.data_ptr(), ep_idx.data_ptr(), int(ep_idx.numel()), ep_acc.data_ptr(), stream))
 
 
-@pytest.mark.parametrize("N,T,noise", [(2048, 80, False), (63, 100, False), (256, 40, True)])
-def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise):
+@pytest.mark.parametrize("N,T,noise,send_timeouts", [(2048, 80, False, True), (63, 100, False, True), (256, 40, True, True), (128, 30, False, False)])
+def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise, send_timeouts):
     """nm_rollout(K = T) against T x [nm_rollout_act, nm_step, nm_ppo_record] from the same start (random episode lengths, so that time-outs,
     falls and command resamples happen inside the rollout; the third case with observation noise on; N = 63: steps WITHOUT any reset occur, where extras['time_outs'] and
     extras['episode'] are stale and rsl_rl's process_env_step / the runner's running sum use the stale values - and half a wave is empty).
@@ -88,6 +89,7 @@ def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise
     gamma = 0.99
     envs = [make_env(N, seed=11, noise=noise), make_env(N, seed=11, noise=noise)]     # noise: cfg.noise.add_noise (env.py:304-305), keyed by the step count of the env
     for e in envs:
+        e.cfg.env.send_timeouts = send_timeouts       # False: extras carry no 'time_outs' (env.py:369), PPO.process_env_step adds no bootstrap term
         e.reset()
         torch.manual_seed(3)
         e.episode_length_buf = torch.randint(0, 1250, (N,), device=DEV, dtype=torch.int64)
@@ -141,7 +143,9 @@ def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise
     a = torch.rand(N, 18, device=DEV) * 2 - 1
     for _ in range(3):
         ra, rb = envs[0].step(a), envs[1].step(a)
-        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[2], rb[2]) and torch.equal(ra[3], rb[3]) and torch.equal(ra[4]["time_outs"], rb[4]["time_outs"])
+        assert torch.equal(ra[0], rb[0]) and torch.equal(ra[2], rb[2]) and torch.equal(ra[3], rb[3]) and ("time_outs" in ra[4]) == send_timeouts
+        if send_timeouts:
+            assert torch.equal(ra[4]["time_outs"], rb[4]["time_outs"])
     for e in envs:
         e.close()
 
