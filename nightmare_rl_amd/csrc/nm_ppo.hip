@@ -1,6 +1,6 @@
 // nm_ppo.hip - PPO mini-batch update of rsl_rl v1.0.2 (`algorithms/ppo.py` PPO.update; caller reference train.py:54) on hand-written
 // kernels: forward of actor and critic, the clipped-surrogate / clipped-value / entropy losses, the whole backward pass, gradient-norm
-// clipping, the KL-adaptive learning rate and Adam - TWO launches per mini-batch (k_ppo_fwdbwd*, k_ppo_step), no host synchronisation, instead of ~60 framework
+// clipping, the KL-adaptive learning rate and Adam - TWO launches per mini-batch (k_ppo_fwdbwd / k_ppo_fwdbwd_split, k_ppo_step), no host synchronisation, instead of ~60 framework
 // launches (elementwise chains on [81920 x 54] activations + library GEMMs with K = 82 k).
 //
 // The two MLPs (reference envs/nightmare_v3_config.py:107-109: 66 -> 54 -> 42 -> 30 -> 18 and -> 1, ELU) run as ONE merged network:
@@ -41,7 +41,6 @@ constexpr int kThreads = 512, kWaves = 8;
 constexpr int kSlots = 16;                 // dW tiles a wave can own
 constexpr int kMaxA = 32;                  // actions (<=)
 constexpr int kNS = 40;                    // per-workgroup scalars: dstd[32], kl, surrogate, value loss, count, pad
-constexpr int kFastWaves = 4, kFastSlots = 32;
 
 struct PpoNet {
   int n_layers;
@@ -53,7 +52,9 @@ struct PpoNet {
   const f32x4* pf[kL];         // forward packing   [O tile][k group][lane]
   const f32x4* pb[kL];         // backward packing  [K tile][o group][lane]
   int slot[kWaves][kSlots];    // dW tiles of wave w: layer | o tile << 4 | k tile << 8, -1 = none (tile g of the network goes to wave g % 8)
-  int slot2[kFastWaves][kFastSlots];   // fast kernel: dW tiles of wave w, slot order = layer by layer: o tile | k tile << 4, -1 = none
+  int slot4[4][16];                    // split kernel (k_ppo_fwdbwd_split): dW tiles of row-group wave g of either net, layer by layer: o tile | k tile << 4, -1 = none
+  const f32x4* sf[2];                  // split kernel: per net (actor, critic), forward fragments in consumption order
+  const f32x4* sb[2];                  // ... and the dX fragments
 };
 struct PpoBatch {
   const float *obs, *actions, *old_mu, *old_sigma, *old_logp, *adv, *ret, *tval, *std;
@@ -267,17 +268,22 @@ __global__ void __launch_bounds__(kThreads) k_ppo_fwdbwd(PpoNet net, PpoBatch bt
 
 
 // ------------------------------------------------------------------------------------------------ fast path
-// For the reference's network shape (three hidden layers, known at compile time) the mini-batch runs through k_ppo_fwdbwd_fast:
+// For the reference's network shape (three hidden layers, known at compile time) the mini-batch runs through k_ppo_fwdbwd_split and
+// the collection step through k_ppo_act_fast. Common to both:
 //   * a wave owns 16 rows from observation to deltas; activations and deltas never leave its registers. Every product is computed
 //     transposed, Y' = W X': the weights are the A operand (straight from L2, 16 B per lane per 4 MFMAs), the activations the B
 //     operand, and the result lands as lane (row r, q) <- features 16 t + 4 q + reg of tile t - exactly the B-operand layout of the
 //     next layer (feature order inside a k-step is free as long as the packed weights use the same one) and of dX = W' D'.
 //     No LDS, no barrier, no cross-wave dependency in forward, loss head and dX.
-//   * tiles of the merged matrices that hold no parameter (actor x critic blocks) are skipped at compile time: 85 of 109.
 //   * only dW needs the batch on the k axis: per layer the four waves of a workgroup park their transposed delta / activation tiles
 //     in LDS (conflict-free b32 writes, b128 reads), one barrier, then each wave accumulates its share of the layer's dW tiles over
 //     the workgroup's 64 rows; two buffers alternate between layers, so that barrier is the only one.
-//   One workgroup (4 waves, 1 per SIMD, 512 registers each) per CU.
+// (Round 4 replaced the merged four-wave kernel of rounds 2-3 - one 512-register wave per SIMD, 146 us per 81 920-row mini-batch - by
+// the per-net kernel below: 133 us. k_ppo_act_fast still runs the merged network: Shape4::nz skips its actor x critic tiles.)
+// Workgroup barrier for data exchanged through LDS only: wait for this wave's LDS traffic, then s_barrier. __syncthreads() also drains
+// the vector-memory queue (a workgroup-scope release has to assume global memory): at the layer-1 barrier that is the next pass's rows
+// (an HBM gather) and at every barrier the weight fragments prefetched across it - the ring would be waited for, not run under.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 template <int N, class F, int... Is> __device__ __forceinline__ void sfor_impl(F&& f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
 template <int N, class F> __device__ __forceinline__ void sfor(F&& f) { sfor_impl<N>(f, std::make_integer_sequence<int, N>{}); }
 
@@ -304,11 +310,6 @@ struct Shape4 {
     return actor || critic || bias;
   }
   static constexpr __host__ __device__ int ntiles(int l) { int n = 0; for (int to = 0; to < P(l + 1) / 16; to++) for (int tk = 0; tk < P(l) / 16; tk++) n += nz(l, to, tk); return n; }
-  static constexpr __host__ __device__ int slots(int l) { return (ntiles(l) + kFastWaves - 1) / kFastWaves; }
-  static constexpr __host__ __device__ int slotbase(int l) { int n = 0; for (int i = 0; i < l; i++) n += slots(i); return n; }
-  static constexpr __host__ __device__ int nslots() { return slotbase(NL); }
-  // floats of exchange buffer b (layers of parity b)
-  static constexpr __host__ __device__ int xfloats(int b) { int m = 0; for (int l = b; l < NL; l += 2) { const int n = (P(l) + P(l + 1)) / 16 * kFastWaves * 320; m = n > m ? n : m; } return m; }
 };
 typedef float f32x4u __attribute__((ext_vector_type(4), aligned(4)));
 // -DNM_PPO_STAMPS (measurement builds only): lane 0 of wave 0 adds the s_memtime ticks since its previous stamp to g_ppo_stamps[k]
@@ -355,22 +356,92 @@ template <class S> struct Seq {
   static constexpr __host__ __device__ int entry(bool fwd, int i) { return walk(fwd, 1, i); }
   static constexpr __host__ __device__ int index(bool fwd, int l, int to, int tk) { return walk(fwd, 2, l | (to << 4) | (tk << 8)); }
 };
-constexpr int kRing = 12;
+constexpr int kRing = 12;     // weight fragments in flight in k_ppo_act_fast
+
+// k_ppo_fwdbwd_split: the same mini-batch pass with TWO waves per SIMD. k_ppo_fwdbwd_fast keeps one 512-register wave per SIMD, so every
+// stall of that wave - the ELU / loss-head VALU between MFMA chains, the LDS round trips of the dW operands, barriers, the weight ring's
+// L2 latency - is idle matrix-pipe time (measured: 50 % MFMA busy, 2x the MFMA floor). Giving each SIMD a second wave needs the per-wave
+// state to fit 256 registers; rows cannot be split further (an MFMA tile is 16 rows), but the NETWORK can: actor and critic are independent
+// chains that share only the observation. A workgroup is 4 waves = 4 row groups of 16 rows of ONE net (even blocks: actor, odd blocks:
+// critic); it runs that net's forward, its part of the loss head, dX and dW - half the activations, deltas, accumulators and weight
+// fragments of a merged wave, the same total MFMA work per row (no block-diagonal padding tiles at all) - and TWO workgroups share a CU
+// (80 KB of LDS and 256 registers each). They are independent: no common barrier, so they drift out of phase and one's stalls are the
+// other's matrix-pipe time. (The same split inside ONE eight-wave workgroup was measured first: its common barriers keep the two waves
+// of a SIMD in lock step - both in their MFMA phases, then both in their waits - and it gained nothing: 45 % MFMA busy.)
+// Both nets have the same tile shape (the critic's last layer is padded to the actor's), so both roles run ONE code path on different
+// weights; only the loss head branches on the role (workgroup-uniform).
+//   * weights: per net, fragments stored in the order the wave consumes them (nm_ppo_create: sfi / sbi), so the stream is linear;
+//   * exchange buffers: per layer the net's delta and input tiles of the 4 row groups; two buffers alternate between layers as in the
+//     four-wave kernel: one barrier per layer;
+//   * the partial gradient of blocks 2 v and 2 v + 1 goes to partial row v at the merged layout's positions (the two nets' entries are
+//     disjoint), so k_ppo_step / k_ppo_reduce and the parameter map do not change.
+template <class S> struct Split {
+  static constexpr int NL = S::NL, NG = 4;                     // row groups (waves per net)
+  static constexpr __host__ __device__ int up16(int x) { return (x + 15) & ~15; }
+  static constexpr __host__ __device__ int in(int l) { return S::ain(l); }                          // real inputs of layer l (both nets)
+  static constexpr __host__ __device__ int out(int l, int net) { return net ? S::cout(l) : S::aout(l); }
+  static constexpr __host__ __device__ int P(int l) { return l == NL ? up16(S::aout(NL - 1)) : up16(in(l) + 1); }   // padded input width of layer l / output width
+  static constexpr __host__ __device__ int nkt(int l) { return P(l) / 16; }
+  static constexpr __host__ __device__ int nto(int l) { return P(l + 1) / 16; }
+  static constexpr __host__ __device__ int maxT() { int m = 0; for (int l = 0; l <= NL; l++) m = P(l) / 16 > m ? P(l) / 16 : m; return m; }
+  static constexpr __host__ __device__ bool same() {
+    for (int l = 1; l < NL; l++) if (S::ain(l) != S::cin(l)) return false;
+    return S::cout(NL - 1) <= S::aout(NL - 1);
+  }
+  // consumption order of the weight fragments. forward: layer 0..NL-1 | pairs of output tiles | k tile | even, odd output tile;
+  // dX: layer NL-1..1 | pairs of k tiles | o tile | even, odd k tile  (the two tiles of a pair are independent accumulation chains)
+  static constexpr __host__ __device__ int nf() { int n = 0; for (int l = 0; l < NL; l++) n += nto(l) * nkt(l); return n; }
+  static constexpr __host__ __device__ int nb() { int n = 0; for (int l = 1; l < NL; l++) n += nto(l) * nkt(l); return n; }
+  static constexpr __host__ __device__ int fidx(int l, int to, int tk) {
+    int n = 0;
+    for (int i = 0; i < l; i++) n += nto(i) * nkt(i);
+    const int p = to / 2, width = (2 * p + 1 < nto(l)) ? 2 : 1;
+    return n + 2 * p * nkt(l) + tk * width + (to & 1);
+  }
+  static constexpr __host__ __device__ int bidx(int l, int to, int tk) {
+    int n = 0;
+    for (int i = NL - 1; i > l; i--) n += nto(i) * nkt(i);
+    const int p = tk / 2, width = (2 * p + 1 < nkt(l)) ? 2 : 1;
+    return n + 2 * p * nto(l) + to * width + (tk & 1);
+  }
+  static constexpr __host__ __device__ int slots(int l) { return (nto(l) * nkt(l) + NG - 1) / NG; }
+  static constexpr __host__ __device__ int slotbase(int l) { int n = 0; for (int i = 0; i < l; i++) n += slots(i); return n; }
+  static constexpr __host__ __device__ int nslots() { return slotbase(NL); }
+  // exchange tiles of layer l: nto deltas + nkt inputs
+  static constexpr __host__ __device__ int xtiles(int l) { return nto(l) + nkt(l); }
+  static constexpr __host__ __device__ int xfloats(int b) { int m = 0; for (int l = b; l < NL; l += 2) { const int n = xtiles(l) * NG * 320; m = n > m ? n : m; } return m; }
+};
+constexpr int kSplitWaves = 4, kSplitSlots = 16;
+#ifndef NM_PPO_SRING
+#define NM_PPO_SRING 10      // weight fragments in flight per wave (6 .. 14 measure the same)
+#endif
+#ifndef NM_PPO_ABL           // measurement builds only (wrong results): 1 no weight stream, 2 no dW, 4 no parking
+#define NM_PPO_ABL 0
+#endif
+// The weight ring relies on vmcnt retiring in order: fragment i is waited for with vmcnt(number of fragments requested after it). The
+// scheduler treats the loads as independent and moves them away from the MFMAs they were written next to (measured: the waits counted
+// DOWN 10, 9, .. 0 through a layer while the refills sat in a cluster behind it - the ring drained); a scheduling barrier after every
+// request keeps each request at its place in the MFMA stream.
+#define NM_PPO_PIN() __builtin_amdgcn_sched_barrier(0)
 
 template <class S>
-__global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net, PpoBatch bt, float* __restrict__ partial) {
-  typedef Seq<S> Q;
-  constexpr int NL = S::NL, MT = S::maxT(), PO = S::P(NL) / 16, AO = S::aout(NL - 1), I = S::Kr(0), T0 = S::P(0) / 16;
-  constexpr int NF = Q::count(true), NB = Q::count(false);
+__global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet net, PpoBatch bt, float* __restrict__ partial) {
+  typedef Split<S> X;
+  constexpr int NL = S::NL, NG = X::NG, MT = X::maxT(), PO = X::P(NL) / 16, AO = S::aout(NL - 1), I = X::in(0), T0 = X::nkt(0);
+  constexpr int NF = X::nf(), NB = X::nb(), kR = NM_PPO_SRING;
   constexpr int kXT = 20, kTileF = 16 * kXT;       // an exchange tile: 16 features x (16 rows + 4 pad) floats
-  static_assert(S::nslots() <= kFastSlots && AO + 1 <= 32 && PO <= 2 && NF >= kRing && NB >= kRing, "shape outside the fast kernel's limits");
-  __shared__ __attribute__((aligned(16))) float xb0[S::xfloats(0)];
-  __shared__ __attribute__((aligned(16))) float xb1[S::xfloats(1)];
-  __shared__ float hsum[kFastWaves][40];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r = lane & 15, q = lane >> 4;
+  static_assert(X::same() && X::nslots() <= kSplitSlots && AO <= 32 && PO <= 2 && NF >= kR && NB >= kR, "shape outside the split kernel's limits");
+  static_assert((X::xfloats(0) + X::xfloats(1)) * 4 <= 80 * 1024 && X::xfloats(0) >= kSplitWaves * 40, "two workgroups must fit the LDS of a CU");
+  __shared__ __attribute__((aligned(16))) float xb0[X::xfloats(0)];
+  __shared__ __attribute__((aligned(16))) float xb1[X::xfloats(1)];
+  float (*hsum)[40] = reinterpret_cast<float (*)[40]>(xb0);      // the closing sums reuse the exchange buffer (the two buffers are exactly 80 KB)
+  const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6), r = lane & 15, q = lane >> 4;
+  const int g = w, nt = blockIdx.x & 1;            // row group; net (0 actor, 1 critic): workgroup-uniform
+  const int vb = blockIdx.x >> 1, nvb = gridDim.x >> 1;      // blocks 2 v and 2 v + 1 walk the same passes v, v + nvb, ...
+  const bool critic = nt != 0;
   const int prow = (r & 3) * 4 + (r >> 2);         // rows are parked as [row mod 4][row div 4]: one b128 read = rows 4 s + q', s = 0..3
-  f32x4 gw[S::nslots()];
-  sfor<S::nslots()>([&](auto i) { gw[i] = f32x4{0, 0, 0, 0}; });
+  f32x4 gw[X::nslots()];
+  sfor<X::nslots()>([&](auto i) { gw[i] = f32x4{0, 0, 0, 0}; });
   float a_dstd[PO][4], a_kl = 0.0f, a_surr = 0.0f, a_vl = 0.0f;
   float sdv[PO][4];
   sfor<PO>([&](auto T) {
@@ -378,16 +449,22 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
 #pragma unroll
     for (int reg = 0; reg < 4; reg++) { a_dstd[t][reg] = 0.0f; const int f = 16 * t + 4 * q + reg; sdv[t][reg] = f < AO ? bt.std[f] : 1.0f; }
   });
-  const int npass = (bt.B + 16 * kFastWaves - 1) / (16 * kFastWaves);
+  const int npass = (bt.B + 16 * NG - 1) / (16 * NG);
 #ifdef NM_PPO_STAMPS
   unsigned long long t_last = __builtin_amdgcn_s_memtime();
 #endif
-  // per-row data of a pass: the observation tile (B operand of layer 0) and what the loss head needs. Loaded one pass ahead - these
-  // come from HBM, and vmcnt retires in order: a wait for the first weight fragment would otherwise sit behind their full latency.
-  struct RowData { f32x4 obs[T0], act[PO], omu[PO], osd[PO]; float adv, olp, ret, tv; };
+  // per-row data of a pass. The observation tile (B operand of layer 0) is loaded one pass ahead; what the role's loss head needs is
+  // requested inside the forward pass, at the first layer boundary by which every forward weight fragment has been requested (vmcnt
+  // retires in order: an HBM gather issued earlier would hold up every wait for a fragment behind it; held a whole pass ahead it costs
+  // 28 registers that the compiler spills and reloads one by one, each reload behind a full vmcnt(0))
+  struct RowData { f32x4 obs[T0]; };
+  struct HeadData { f32x4 act[PO], omu[PO], osd[PO]; float adv, olp, ret, tv; };
+  auto row_of = [&](int pass) -> size_t {
+    const int row = (pass * NG + g) * 16 + r;
+    return row < bt.B ? (bt.rows ? (size_t)bt.rows[row] : (size_t)row) : 0;
+  };
   auto load_rows = [&](int pass, RowData& rd) {
-    const int row = (pass * kFastWaves + w) * 16 + r;
-    const size_t lrow = row < bt.B ? (bt.rows ? (size_t)bt.rows[row] : (size_t)row) : 0;
+    const size_t lrow = row_of(pass);
     sfor<T0>([&](auto T) {
       constexpr int t = T;
       if constexpr (16 * t + 16 <= I) {
@@ -397,63 +474,77 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
         for (int reg = 0; reg < 4; reg++) { const int f = 16 * t + 4 * q + reg; const float v = bt.obs[lrow * I + (f < I ? f : 0)]; rd.obs[t][reg] = f < I ? v : (f == I ? 1.0f : 0.0f); }
       }
     });
-    sfor<PO>([&](auto T) {
-      constexpr int t = T;
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const int f = 16 * t + 4 * q + reg;
-        const size_t at = lrow * AO + (f < AO ? f : 0);
-        rd.act[t][reg] = bt.actions[at]; rd.omu[t][reg] = bt.old_mu[at]; rd.osd[t][reg] = bt.old_sigma[at];
-      }
-    });
-    rd.adv = bt.adv[lrow]; rd.olp = bt.old_logp[lrow]; rd.ret = bt.ret[lrow]; rd.tv = bt.tval[lrow];
   };
+  auto load_head = [&](int pass, HeadData& rd) {
+    const size_t lrow = row_of(pass);
+    if (!critic) {
+      sfor<PO>([&](auto T) {
+        constexpr int t = T;
+#pragma unroll
+        for (int reg = 0; reg < 4; reg++) {
+          const int f = 16 * t + 4 * q + reg;
+          const size_t at = lrow * AO + (f < AO ? f : 0);
+          rd.act[t][reg] = bt.actions[at]; rd.omu[t][reg] = bt.old_mu[at]; rd.osd[t][reg] = bt.old_sigma[at];
+        }
+      });
+      rd.adv = bt.adv[lrow]; rd.olp = bt.old_logp[lrow];
+    } else {
+      rd.ret = bt.ret[lrow]; rd.tv = bt.tval[lrow];
+    }
+  };
+  // the first layer at whose start all forward fragments are in flight or consumed
+  constexpr int LH = [] { int n = 0; for (int l = 0; l < NL; l++) { if (n + kR >= NF) return l; n += X::nto(l) * X::nkt(l); } return NL - 1; }();
   RowData nx;
-  f32x4 ring[kRing];
-  int wlane = lane;            // made opaque once per pass: the 135 weight fragments are re-read from L2 every pass, not hoisted out of the loop into 540 registers
+  f32x4 ring[kR];
+  const f32x4* __restrict__ WF = net.sf[nt];
+  const f32x4* __restrict__ WB = net.sb[nt];
+  unsigned wlane = lane;       // made opaque once per pass: the weight fragments are re-read from L2 every pass, not hoisted out of the loop
   asm volatile("" : "+v"(wlane));
   auto wfrag = [&](auto FWD, auto IDX) -> f32x4 {
     constexpr bool fwd = FWD;
-    constexpr int e = Q::entry(fwd, IDX), l = e & 15, to = (e >> 4) & 15, tk = e >> 8;
-    if constexpr (fwd) return net.pf[l][(to * (S::P(l) / 16) + tk) * 64 + wlane];
-    else return net.pb[l][(tk * (S::P(l + 1) / 16) + to) * 64 + wlane];
+    constexpr int i = IDX;
+#if NM_PPO_ABL & 1      // measurement only: no weight stream (wrong results)
+    return f32x4{__int_as_float(wlane), 1.0f, 0.5f, 0.25f};
+#else
+    return (fwd ? WF : WB)[i * 64 + wlane];
+#endif
   };
-  if (blockIdx.x < npass) load_rows(blockIdx.x, nx);
-  sfor<kRing>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); });
-  for (int pass = blockIdx.x; pass < npass; pass += gridDim.x) {
+  if (vb < npass) load_rows(vb, nx);
+  sfor<kR>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); NM_PPO_PIN(); });
+  for (int pass = vb; pass < npass; pass += nvb) {
     PPO_STAMP(15);
-    const int row = (pass * kFastWaves + w) * 16 + r;
+    const int row = (pass * NG + g) * 16 + r;
     const bool live = row < bt.B;
-    const RowData cu = nx;
+    HeadData cu;
     f32x4 a[NL][MT], d[2][MT], out[PO];
-    sfor<T0>([&](auto T) { a[0][T] = live ? cu.obs[T] : f32x4{0, 0, 0, 0}; });
+    sfor<T0>([&](auto T) { a[0][T] = live ? nx.obs[T] : f32x4{0, 0, 0, 0}; });
     PPO_STAMP(0);
     // ---- forward
     sfor<NL>([&](auto L) {
-      constexpr int l = L, nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
+      constexpr int l = L, nkt = X::nkt(l), nto = X::nto(l);
       constexpr bool last = l == NL - 1;
       if constexpr (l > 0) PPO_STAMP(l);
+      if constexpr (l == LH) load_head(pass, cu);
       sfor<(nto + 1) / 2>([&](auto PP) {
         constexpr int to0 = 2 * PP, to1 = to0 + 1;
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         sfor<nkt>([&](auto TK) {
           constexpr int tk = TK;
-          constexpr bool z0 = S::nz(l, to0, tk), z1 = to1 < nto && S::nz(l, to1, tk);
           f32x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
-          if constexpr (z0) {
-            constexpr int i = Q::index(true, l, to0, tk);
-            w0 = ring[i % kRing];
-            if constexpr (i + kRing < NF) ring[i % kRing] = wfrag(std::true_type{}, std::integral_constant<int, (i + kRing < NF ? i + kRing : 0)>{});
+          {
+            constexpr int i = X::fidx(l, to0, tk);
+            w0 = ring[i % kR];
+            if constexpr (i + kR < NF) { ring[i % kR] = wfrag(std::true_type{}, std::integral_constant<int, (i + kR < NF ? i + kR : 0)>{}); NM_PPO_PIN(); }
           }
-          if constexpr (z1) {
-            constexpr int i = Q::index(true, l, to1, tk);
-            w1 = ring[i % kRing];
-            if constexpr (i + kRing < NF) ring[i % kRing] = wfrag(std::true_type{}, std::integral_constant<int, (i + kRing < NF ? i + kRing : 0)>{});
+          if constexpr (to1 < nto) {
+            constexpr int i = X::fidx(l, to1 < nto ? to1 : to0, tk);
+            w1 = ring[i % kR];
+            if constexpr (i + kR < NF) { ring[i % kR] = wfrag(std::true_type{}, std::integral_constant<int, (i + kR < NF ? i + kR : 0)>{}); NM_PPO_PIN(); }
           }
 #pragma unroll
           for (int j = 0; j < 4; j++) {
-            if constexpr (z0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[l][tk][j], acc0, 0, 0, 0);
-            if constexpr (z1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[l][tk][j], acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[l][tk][j], acc0, 0, 0, 0);
+            if constexpr (to1 < nto) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[l][tk][j], acc1, 0, 0, 0);
           }
         });
         auto finish = [&](auto TO, const f32x4& acc) {
@@ -461,11 +552,18 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
           if constexpr (last) {
             out[to] = acc;
           } else {
+            constexpr int NO = X::in(l + 1);      // real outputs of this layer = real inputs of the next (both nets)
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-              const int col = 16 * to + 4 * q + reg;
               const float v = acc[reg];
-              a[l + 1][to][reg] = col < S::Or(l) ? (v > 0.0f ? v : __expf(v) - 1.0f) : (col == S::Or(l) ? 1.0f : 0.0f);   // ELU | bias carrier | padding
+              const float e = __expf(v) - 1.0f, y = v > 0.0f ? v : e;
+              if constexpr (16 * to + 16 <= NO) {
+                a[l + 1][to][reg] = y;
+              } else {
+                const int col = 16 * to + 4 * q + reg;
+                const float pad = col == NO ? 1.0f : 0.0f;
+                a[l + 1][to][reg] = col < NO ? y : pad;   // ELU | bias carrier | padding
+              }
             }
           }
         };
@@ -474,17 +572,21 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
       });
     });
     PPO_STAMP(4);
-    sfor<kRing>([&](auto i) { ring[i] = wfrag(std::false_type{}, i); });      // the dX fragments start to arrive behind the loss head
-    // ---- loss head: lane (row r, q) holds outputs 16 t + 4 q + reg; per-row sums cross the four q lanes
-    {
+    // ---- loss head, by role. Actor: lane (row r, q) holds means 16 t + 4 q + reg, per-row sums cross the four q lanes. Critic: the
+    // value is output column 0 (tile 0, register 0 of the q = 0 lanes).
+    sfor<PO>([&](auto T) { d[0][T] = f32x4{0, 0, 0, 0}; });
+    if (!critic) {
       float lp = 0.0f, kl = 0.0f;
+      float sd_[PO][4];
       sfor<PO>([&](auto T) {
         constexpr int t = T;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
+          sd_[t][reg] = sdv[t][reg];
+          asm volatile("" : "+v"(sd_[t][reg]));      // (left to itself the compiler hoists every function of the loop-invariant sigmas out of the pass loop and spills them)
           const int f = 16 * t + 4 * q + reg;
           if (f < AO) {
-            const float mu = out[t][reg], sd = sdv[t][reg], osd = cu.osd[t][reg], omu = cu.omu[t][reg];
+            const float mu = out[t][reg], sd = sd_[t][reg], osd = cu.osd[t][reg], omu = cu.omu[t][reg];
             const float z = (cu.act[t][reg] - mu) / sd;
             lp += -0.5f * z * z - __logf(sd) - 0.9189385332046727f;
             kl += __logf(sd / osd + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) / (2.0f * sd * sd) - 0.5f;
@@ -508,50 +610,63 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
           const int f = 16 * t + 4 * q + reg;
-          float dd = 0.0f;
           if (live && f < AO) {
-            const float mu = out[t][reg], sd = sdv[t][reg], am = cu.act[t][reg] - mu;
-            dd = dlogp * am / (sd * sd);
+            const float mu = out[t][reg], sd = sd_[t][reg], am = cu.act[t][reg] - mu;
+            d[0][t][reg] = dlogp * am / (sd * sd);
             a_dstd[t][reg] += dlogp * (am * am / (sd * sd * sd) - 1.0f / sd);
-          } else if (live && f == AO) {
-            const float v = out[t][reg];
-            float dv, vl;
-            if (bt.clip_value) {
-              const float dvt = v - cu.tv, vc = cu.tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
-              const float l1 = (v - cu.ret) * (v - cu.ret), l2 = (vc - cu.ret) * (vc - cu.ret);
-              const bool in2 = dvt > -bt.clip && dvt < bt.clip;
-              const float h1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), h2 = 1.0f - h1;
-              vl = fmaxf(l1, l2);
-              dv = h1 * 2.0f * (v - cu.ret) + h2 * (in2 ? 2.0f * (vc - cu.ret) : 0.0f);
-            } else {
-              vl = (cu.ret - v) * (cu.ret - v);
-              dv = 2.0f * (v - cu.ret);
-            }
-            a_vl += vl;
-            dd = dv * bt.vcoef * bt.inv_B;
           }
-          d[0][t][reg] = dd;
         }
       });
+    } else if (live && q == 0) {
+      const float v = out[0][0];
+      float dv, vl;
+      if (bt.clip_value) {
+        const float dvt = v - cu.tv, vc = cu.tv + fminf(fmaxf(dvt, -bt.clip), bt.clip);
+        const float l1 = (v - cu.ret) * (v - cu.ret), l2 = (vc - cu.ret) * (vc - cu.ret);
+        const bool in2 = dvt > -bt.clip && dvt < bt.clip;
+        const float h1 = l1 > l2 ? 1.0f : (l1 == l2 ? 0.5f : 0.0f), h2 = 1.0f - h1;
+        vl = fmaxf(l1, l2);
+        dv = h1 * 2.0f * (v - cu.ret) + h2 * (in2 ? 2.0f * (vc - cu.ret) : 0.0f);
+      } else {
+        vl = (cu.ret - v) * (cu.ret - v);
+        dv = 2.0f * (v - cu.ret);
+      }
+      a_vl += vl;
+      d[0][0][0] = dv * bt.vcoef * bt.inv_B;
     }
     PPO_STAMP(5);
+    // the dX fragments are requested only now: in flight across the loss head they are 4 x kR registers that the head's divisions and
+    // logarithms have no room for (the spill reloads each waited for the whole ring)
+    sfor<kR>([&](auto i) { ring[i] = wfrag(std::false_type{}, i); NM_PPO_PIN(); });
     // ---- backward
     sfor<NL>([&](auto LL) {
       constexpr int l = NL - 1 - LL, cur = LL & 1, nxt = cur ^ 1;
-      constexpr int nkt = S::P(l) / 16, nto = S::P(l + 1) / 16;
+      constexpr int nkt = X::nkt(l), nto = X::nto(l);
+      // layout of the layer's exchange buffer: [delta tiles][row group] then [input tiles][row group]
       float* xb = (l & 1) ? xb1 : xb0;
+      constexpr int dbase = 0, abase = nto;
       if constexpr (LL > 0) PPO_STAMP(5 + 2 * LL);
       // park this wave's deltas and layer inputs, transposed, for the workgroup's dW
+#if NM_PPO_ABL & 4      // measurement only: no parking
+      if (bt.B < 0)
+#endif
+      {
       sfor<nto>([&](auto T) {
         constexpr int t = T;
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) xb[(t * kFastWaves + w) * kTileF + (4 * q + reg) * kXT + prow] = d[cur][t][reg];
+        for (int reg = 0; reg < 4; reg++) xb[((dbase + t) * NG + g) * kTileF + (4 * q + reg) * kXT + prow] = d[cur][t][reg];
       });
+      if constexpr (l == 0) {       // the observation tile is not kept across the pass (20 registers): read it again (L2) for layer 0's dW
+        RowData ob;
+        load_rows(pass, ob);
+        sfor<T0>([&](auto T) { a[0][T] = live ? ob.obs[T] : f32x4{0, 0, 0, 0}; });
+      }
       sfor<nkt>([&](auto T) {
         constexpr int t = T;
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) xb[((nto + t) * kFastWaves + w) * kTileF + (4 * q + reg) * kXT + prow] = a[l][t][reg];
+        for (int reg = 0; reg < 4; reg++) xb[((abase + t) * NG + g) * kTileF + (4 * q + reg) * kXT + prow] = a[l][t][reg];
       });
+      }
       // d_{l-1} = (W' d_l) * ELU'(a_l): registers only
       if constexpr (l > 0) {
         sfor<(nkt + 1) / 2>([&](auto PP) {
@@ -559,31 +674,31 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
           f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
           sfor<nto>([&](auto TO) {
             constexpr int to = TO;
-            constexpr bool z0 = S::nz(l, to, tk0), z1 = tk1 < nkt && S::nz(l, to, tk1);
             f32x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
-            if constexpr (z0) {
-              constexpr int i = Q::index(false, l, to, tk0);
-              w0 = ring[i % kRing];
-              if constexpr (i + kRing < NB) ring[i % kRing] = wfrag(std::false_type{}, std::integral_constant<int, (i + kRing < NB ? i + kRing : 0)>{});
+            {
+              constexpr int i = X::bidx(l, to, tk0);
+              w0 = ring[i % kR];
+              if constexpr (i + kR < NB) { ring[i % kR] = wfrag(std::false_type{}, std::integral_constant<int, (i + kR < NB ? i + kR : 0)>{}); NM_PPO_PIN(); }
             }
-            if constexpr (z1) {
-              constexpr int i = Q::index(false, l, to, tk1);
-              w1 = ring[i % kRing];
-              if constexpr (i + kRing < NB) ring[i % kRing] = wfrag(std::false_type{}, std::integral_constant<int, (i + kRing < NB ? i + kRing : 0)>{});
+            if constexpr (tk1 < nkt) {
+              constexpr int i = X::bidx(l, to, tk1 < nkt ? tk1 : tk0);
+              w1 = ring[i % kR];
+              if constexpr (i + kR < NB) { ring[i % kR] = wfrag(std::false_type{}, std::integral_constant<int, (i + kR < NB ? i + kR : 0)>{}); NM_PPO_PIN(); }
             }
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-              if constexpr (z0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], d[cur][to][j], acc0, 0, 0, 0);
-              if constexpr (z1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], d[cur][to][j], acc1, 0, 0, 0);
+              acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], d[cur][to][j], acc0, 0, 0, 0);
+              if constexpr (tk1 < nkt) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], d[cur][to][j], acc1, 0, 0, 0);
             }
           });
           auto finish = [&](auto TK, const f32x4& acc) {
             constexpr int tk = TK;
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
-              const int col = 16 * tk + 4 * q + reg;
               const float av = a[l][tk][reg];
-              d[nxt][tk][reg] = col < S::Kr(l) ? acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f) : 0.0f;   // ELU'(z) from ELU(z); no gradient into the 1-column
+              const float gr = acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f);                        // ELU'(z) from ELU(z)
+              if constexpr (16 * tk + 16 <= X::in(l)) d[nxt][tk][reg] = gr;
+              else d[nxt][tk][reg] = 16 * tk + 4 * q + reg < X::in(l) ? gr : 0.0f;              // no gradient into the 1-column / padding
             }
           };
           finish(std::integral_constant<int, tk0>{}, acc0);
@@ -594,24 +709,27 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
         // the last weight fragment of this pass has been consumed; what follows (dW of layers 1 and 0) waits on LDS only. Fetch the next
         // pass's rows (HBM) and the first forward fragments now: they retire in order long before the next pass waits on vmcnt
         asm volatile("" : "+v"(wlane));
-        if (pass + (int)gridDim.x < npass) load_rows(pass + gridDim.x, nx);
-        sfor<kRing>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); });
+        if (pass + nvb < npass) load_rows(pass + nvb, nx);
+        sfor<kR>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); NM_PPO_PIN(); });
       }
       PPO_STAMP(6 + 2 * LL);
-      __syncthreads();
-      // dW_l += D' a_l over the 64 rows of the workgroup: this wave's tiles. An unused slot of the table computes on tile (0, 0) into
-      // an accumulator that is never stored - no branch; the operands of slot i + 1 are read from LDS while slot i multiplies.
+      lds_barrier();
+#if NM_PPO_ABL & 2      // measurement only: no dW
+      if (bt.B < 0)
+#endif
+      // dW_l += D' a_l over the 64 rows of the workgroup: this wave's tiles of its net. An unused slot of the table computes on tile (0, 0)
+      // into an accumulator that is never stored - no branch; the operands of slot i + 1 are read from LDS while slot i multiplies.
       {
-        constexpr int NS = S::slots(l), SB = S::slotbase(l);
-        f32x4 fd[2][kFastWaves], fa[2][kFastWaves];
+        constexpr int NS = X::slots(l), SB = X::slotbase(l);
+        f32x4 fd[2][NG], fa[2][NG];
         auto frags = [&](auto SI, auto BUF) {
-          const int code = net.slot2[w][SB + SI], c = code < 0 ? 0 : code;
-          const float* dp = xb + ((c & 15) * kFastWaves) * kTileF + r * kXT + 4 * q;
-          const float* ap = xb + ((nto + (c >> 4)) * kFastWaves) * kTileF + r * kXT + 4 * q;
+          const int code = net.slot4[g][SB + SI], c = code < 0 ? 0 : code;
+          const float* dp = xb + ((dbase + (c & 15)) * NG) * kTileF + r * kXT + 4 * q;
+          const float* ap = xb + ((abase + (c >> 4)) * NG) * kTileF + r * kXT + 4 * q;
 #pragma unroll
-          for (int g = 0; g < kFastWaves; g++) {
-            fd[BUF][g] = *reinterpret_cast<const f32x4*>(dp + g * kTileF);
-            fa[BUF][g] = *reinterpret_cast<const f32x4*>(ap + g * kTileF);
+          for (int gg = 0; gg < NG; gg++) {
+            fd[BUF][gg] = *reinterpret_cast<const f32x4*>(dp + gg * kTileF);
+            fa[BUF][gg] = *reinterpret_cast<const f32x4*>(ap + gg * kTileF);
           }
         };
         frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
@@ -619,29 +737,36 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
           constexpr int si = SI, buf = si & 1;
           if constexpr (si + 1 < NS) frags(std::integral_constant<int, (si + 1 < NS ? si + 1 : 0)>{}, std::integral_constant<int, buf ^ 1>{});
 #pragma unroll
-          for (int g = 0; g < kFastWaves; g++)
+          for (int gg = 0; gg < NG; gg++)
 #pragma unroll
-            for (int j = 0; j < 4; j++) gw[SB + si] = __builtin_amdgcn_mfma_f32_16x16x4f32(fd[buf][g][j], fa[buf][g][j], gw[SB + si], 0, 0, 0);
+            for (int j = 0; j < 4; j++) gw[SB + si] = __builtin_amdgcn_mfma_f32_16x16x4f32(fd[buf][gg][j], fa[buf][gg][j], gw[SB + si], 0, 0, 0);
         });
       }
     });
   }
   PPO_STAMP(13);
-  // ---- this workgroup's partial gradient
-  float* P = partial + (size_t)blockIdx.x * (net.gtotal + kNS);
+  // ---- this workgroup's partial gradient, at the positions of the merged layout (what k_ppo_step / k_ppo_reduce and the map expect):
+  // element (o, k) of net's layer-l matrix -> row o0 + o, column k0 + k of the merged [Op x Kp] block, its bias column -> column Kr
+  float* P = partial + (size_t)vb * (net.gtotal + kNS);
   sfor<NL>([&](auto L) {
     constexpr int l = L;
-    sfor<S::slots(l)>([&](auto SI) {
-      constexpr int slot = S::slotbase(l) + SI;
-      const int code = net.slot2[w][slot];
+    const int no = critic ? S::cout(l) : S::aout(l), o0 = critic ? S::aout(l) : 0, k0 = (critic && l > 0) ? S::ain(l) : 0;
+    sfor<X::slots(l)>([&](auto SI) {
+      constexpr int slot = X::slotbase(l) + SI;
+      const int code = net.slot4[g][slot];
       if (code >= 0) {
-        const int k = 16 * (code >> 4) + r;
+        const int kk = 16 * (code >> 4) + r;
+        const int km = kk < X::in(l) ? k0 + kk : net.Kr[l];
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) P[net.goff[l] + (16 * (code & 15) + 4 * q + reg) * S::P(l) + k] = gw[slot][reg];
+        for (int reg = 0; reg < 4; reg++) {
+          const int o = 16 * (code & 15) + 4 * q + reg;
+          if (o < no && kk <= X::in(l)) P[net.goff[l] + (o0 + o) * net.Kp[l] + km] = gw[slot][reg];
+        }
       }
     });
   });
   for (int o = 1; o < 64; o <<= 1) { a_kl += __shfl_xor(a_kl, o); a_surr += __shfl_xor(a_surr, o); a_vl += __shfl_xor(a_vl, o); }
+  __syncthreads();                       // every wave has left its last dW: the exchange buffer is free for the closing sums
   sfor<PO>([&](auto T) {
     constexpr int t = T;
 #pragma unroll
@@ -654,9 +779,10 @@ __global__ void __launch_bounds__(64 * kFastWaves) k_ppo_fwdbwd_fast(PpoNet net,
   });
   if (lane == 0) { hsum[w][32] = a_kl; hsum[w][33] = a_surr; hsum[w][34] = a_vl; }
   __syncthreads();
-  if (tid < 35) {
+  // the actor block owns scalars 0..33 (d loss / d sigma, KL, surrogate) of the partial row, the critic block scalar 34 (value loss)
+  if (critic ? tid == 34 : tid < 34) {
     float v = 0.0f;
-    for (int g = 0; g < kFastWaves; g++) v += hsum[g][tid];
+    for (int gg = 0; gg < kSplitWaves; gg++) v += hsum[gg][tid];
     P[net.gtotal + tid] = v;
   }
   PPO_STAMP(14);
@@ -836,6 +962,15 @@ __global__ void k_ppo_pack(PpoNet net, const float* __restrict__ Wm_all, int fas
   }
 }
 // flat real parameters -> merged matrices (zero elsewhere: the off-diagonal blocks and the padding never change)
+// the split kernel's packings from the merged matrices: parameter i sits at Wm[map[i]] and goes to sf[sfi[i]] and (layers >= 1) sb[sbi[i]]
+__global__ void k_ppo_pack_split(const float* __restrict__ Wm_all, const int* __restrict__ map, const int* __restrict__ sfi, const int* __restrict__ sbi, int n,
+                                 float* __restrict__ sf, float* __restrict__ sb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n || map[i] < 0) return;
+  const float p = Wm_all[map[i]];
+  sf[sfi[i]] = p;
+  if (sbi[i] >= 0) sb[sbi[i]] = p;
+}
 __global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restrict__ map, int n, float* __restrict__ Wm_all) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n && map[i] >= 0) Wm_all[map[i]] = flat[i];
@@ -938,6 +1073,7 @@ struct StepArgs {
   const int* map; int n;
   float *flat, *m, *v, *grad, *state, *Wm, *n2part;
   float *pf, *pb; const int *pfi, *pbi;        // packings as float arrays + per-parameter positions in them (-1: none)
+  float *sf, *sb; const int *sfi, *sbi;        // the split kernel's per-net packings (null: the network has none)
   unsigned* bar;                                // [0] arrivals, [1] generation
   float ent_coef, inv_B, desired_kl, max_norm, kl_override, b1, b2, eps;
   int adaptive, kl_from_grad, do_reduce;
@@ -1029,7 +1165,10 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a)
     const float bc1 = 1.0f - powf(a.b1, t), bc2 = 1.0f - powf(a.b2, t);
     const float p = a.flat[i] - (lr / bc1) * mi / (sqrtf(vi) / sqrtf(bc2) + a.eps);      // torch.optim.Adam (no amsgrad, no weight decay)
     a.flat[i] = p;
-    if (mp >= 0) { a.Wm[mp] = p; a.pf[a.pfi[i]] = p; a.pb[a.pbi[i]] = p; }
+    if (mp >= 0) {
+      a.Wm[mp] = p; a.pf[a.pfi[i]] = p; a.pb[a.pbi[i]] = p;
+      if (a.sf) { a.sf[a.sfi[i]] = p; const int bi = a.sbi[i]; if (bi >= 0) a.sb[bi] = p; }
+    }
   }
 }
 
@@ -1054,7 +1193,9 @@ __global__ void k_ppo_perm(int* __restrict__ out, int n, int half, uint32_t k0, 
 // ------------------------------------------------------------------------------------------------ handle + C ABI
 struct nm_ppo {
   int device = 0, n_layers = 0, A = 0, nparam = 0, nwg = 0, wm_total = 0;
-  bool fast = false;           // the network has the shape k_ppo_fwdbwd_fast is compiled for
+  bool fast = false;           // the network has the shape k_ppo_fwdbwd_split / k_ppo_act_fast are compiled for
+  float *sf = nullptr, *sb = nullptr;       // split kernel: both nets' forward / dX fragments (actor first)
+  int *sfi = nullptr, *sbi = nullptr;       // per flat parameter: its float position in sf / sb (-1: none)
   PpoNet net;
   std::vector<int> map_host;
   int* map = nullptr;
@@ -1082,7 +1223,7 @@ extern "C" int nm_ppo_destroy(nm_ppo* h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   for (void* p : {(void*)h->map, (void*)h->Wm, (void*)h->pf, (void*)h->pb, (void*)h->partial, (void*)h->grad, (void*)h->state, (void*)h->pfi, (void*)h->pbi, (void*)h->n2part,
-                  (void*)h->bar})
+                  (void*)h->bar, (void*)h->sf, (void*)h->sb, (void*)h->sfi, (void*)h->sbi})
     if (p) (void)hipFree(p);
   delete h;
   return 0;
@@ -1132,7 +1273,6 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
         }
   }
   // the compiled fast path (NM_PPO_GENERIC=1 keeps such a network on the generic kernel: tests, A/B timing)
-  for (int w = 0; w < kFastWaves; w++) for (int i = 0; i < kFastSlots; i++) n.slot2[w][i] = -1;
   {
     typedef RefShape S;
     bool same = n_layers == S::NL && !(std::getenv("NM_PPO_GENERIC") && std::atoi(std::getenv("NM_PPO_GENERIC")) != 0);
@@ -1140,13 +1280,13 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
       same = actor_dims[l] == S::ain(l) && critic_dims[l] == S::cin(l) && actor_dims[l + 1] == S::aout(l) && critic_dims[l + 1] == S::cout(l) &&
              n.Kp[l] == S::P(l) && n.Op[l] == S::P(l + 1);
     h->fast = same;
-    if (same)
-      for (int l = 0; l < S::NL; l++) {      // the layer's parameter-holding tiles in (o tile, k tile) order, a contiguous run per wave
-        int idx = 0;
-        for (int to = 0; to < S::P(l + 1) / 16; to++)
-          for (int tk = 0; tk < S::P(l) / 16; tk++)
-            if (S::nz(l, to, tk)) { n.slot2[idx / S::slots(l)][S::slotbase(l) + idx % S::slots(l)] = to | (tk << 4); idx++; }
-      }
+    for (int w = 0; w < 4; w++) for (int i = 0; i < 16; i++) n.slot4[w][i] = -1;
+    n.sf[0] = n.sf[1] = n.sb[0] = n.sb[1] = nullptr;
+    if (same) {
+      typedef Split<S> X;
+      for (int l = 0; l < S::NL; l++)      // a net's tiles of layer l in (o tile, k tile) order, a contiguous run per row-group wave
+        for (int idx = 0; idx < X::nto(l) * X::nkt(l); idx++) n.slot4[idx / X::slots(l)][X::slotbase(l) + idx % X::slots(l)] = (idx / X::nkt(l)) | ((idx % X::nkt(l)) << 4);
+    }
   }
   // flat parameter -> merged position
   std::vector<int>& map = h->map_host;
@@ -1202,6 +1342,34 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
     PPO_CHK_H(hipMemcpy(h->pfi, pfi.data(), pfi.size() * sizeof(int), hipMemcpyHostToDevice));
     PPO_CHK_H(hipMemcpy(h->pbi, pbi.data(), pbi.size() * sizeof(int), hipMemcpyHostToDevice));
   }
+  if (h->fast) {   // the split kernel's packings: per net its own [out x in + 1] matrices, fragments in the order a wave consumes them
+    typedef Split<RefShape> X;
+    const size_t nfw = (size_t)X::nf() * 64 * 4, nbw = (size_t)X::nb() * 64 * 4;      // floats per net
+    std::vector<int> sfi(map.size(), -1), sbi(map.size(), -1);
+    size_t i = 0;
+    for (int net_i = 0; net_i < 2; net_i++) {
+      const int32_t* d = net_i ? critic_dims : actor_dims;
+      for (int l = 0; l < n_layers; l++) {
+        auto place = [&](int o, int k) {      // element (o, k) of the net's layer-l matrix (k = d[l]: the bias column)
+          { const int t = o / 16, r = o % 16, g = k / 16, q = (k % 16) / 4, j = k % 4;      // forward: lane (r, q) of fragment (t, g), component j
+            sfi[i] = (int)(net_i * nfw + ((size_t)X::fidx(l, t, g) * 64 + q * 16 + r) * 4 + j); }
+          if (l > 0) { const int t = k / 16, r = k % 16, g = o / 16, q = (o % 16) / 4, j = o % 4;      // dX: lane (r, q) of fragment (k tile t, o tile g)
+            sbi[i] = (int)(net_i * nbw + ((size_t)X::bidx(l, g, t) * 64 + q * 16 + r) * 4 + j); }
+          i++;
+        };
+        for (int o = 0; o < d[l + 1]; o++) for (int k = 0; k < d[l]; k++) place(o, k);
+        for (int o = 0; o < d[l + 1]; o++) place(o, d[l]);
+      }
+    }
+    bool ok2 = hipMalloc((void**)&h->sf, 2 * nfw * sizeof(float)) == hipSuccess && hipMalloc((void**)&h->sb, 2 * nbw * sizeof(float)) == hipSuccess &&
+               hipMalloc((void**)&h->sfi, map.size() * sizeof(int)) == hipSuccess && hipMalloc((void**)&h->sbi, map.size() * sizeof(int)) == hipSuccess;
+    if (!ok2) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: hipMalloc failed"); }
+    PPO_CHK_H(hipMemset(h->sf, 0, 2 * nfw * sizeof(float)));
+    PPO_CHK_H(hipMemset(h->sb, 0, 2 * nbw * sizeof(float)));
+    PPO_CHK_H(hipMemcpy(h->sfi, sfi.data(), sfi.size() * sizeof(int), hipMemcpyHostToDevice));
+    PPO_CHK_H(hipMemcpy(h->sbi, sbi.data(), sbi.size() * sizeof(int), hipMemcpyHostToDevice));
+    for (int net_i = 0; net_i < 2; net_i++) { n.sf[net_i] = reinterpret_cast<const f32x4*>(h->sf + net_i * nfw); n.sb[net_i] = reinterpret_cast<const f32x4*>(h->sb + net_i * nbw); }
+  }
   h->fused_step = !(std::getenv("NM_PPO_UNFUSED_STEP") && std::atoi(std::getenv("NM_PPO_UNFUSED_STEP")) != 0);
   PPO_CHK_H(hipMemset(h->partial, 0, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)));
 #undef PPO_CHK_H
@@ -1215,6 +1383,7 @@ static int ppo_pack(nm_ppo* h, hipStream_t s) {
   int most = 0;
   for (int l = 0; l < h->n_layers; l++) most = std::max(most, 2 * (h->net.Op[l] / 16) * (h->net.Kp[l] / 16) * 64);
   hipLaunchKernelGGL(k_ppo_pack, dim3((most + 255) / 256, h->n_layers), dim3(256), 0, s, h->net, h->Wm, h->fast ? 1 : 0);
+  if (h->sf) hipLaunchKernelGGL(k_ppo_pack_split, dim3((h->nparam + 255) / 256), dim3(256), 0, s, h->Wm, h->map, h->sfi, h->sbi, h->nparam, h->sf, h->sb);
   return hipGetLastError() == hipSuccess ? 0 : nm_policy_set_error("nm_ppo: pack launch failed");
 }
 // (re)load the parameters from the flat vector (after load_state_dict, or a step taken elsewhere) and set learning rate / step count
@@ -1254,10 +1423,10 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
   const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + 1 + kRedParams - 1) / kRedParams;
   if (phase == 0 || phase == 1) {     // 1: gradient only
     PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value, rows_dev};
-    const int rows = h->fast ? 16 * kFastWaves : kRows;
+    const int rows = h->fast ? 16 * kSplitWaves : kRows;
     const int ntiles = (B + rows - 1) / rows, grid = ntiles < h->nwg ? ntiles : h->nwg;
     if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
-    if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_fast<RefShape>, dim3(grid), dim3(64 * kFastWaves), 0, s, h->net, bt, h->partial);
+    if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_split<RefShape>, dim3(2 * grid), dim3(64 * kSplitWaves), 0, s, h->net, bt, h->partial);      // two blocks (actor, critic) per partial row
     else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
     if (phase == 1 || !h->fused_step)
       hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
@@ -1267,6 +1436,7 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     a.partial = h->partial; a.nwg = h->nwg; a.stride = stride; a.gtotal = h->net.gtotal; a.map = h->map; a.n = h->nparam;
     a.flat = flat_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev; a.grad = h->grad; a.state = h->state; a.Wm = h->Wm; a.n2part = h->n2part;
     a.pf = reinterpret_cast<float*>(h->pf); a.pb = reinterpret_cast<float*>(h->pb); a.pfi = h->pfi; a.pbi = h->pbi; a.bar = h->bar;
+    a.sf = h->sf; a.sb = h->sb; a.sfi = h->sfi; a.sbi = h->sbi;
     a.ent_coef = entropy_coef; a.inv_B = 1.0f / (float)B; a.desired_kl = desired_kl; a.max_norm = max_grad_norm; a.kl_override = kl_override;
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adaptive = adaptive; a.kl_from_grad = phase == 2 ? 1 : 0; a.do_reduce = phase == 0 ? 1 : 0;
     hipLaunchKernelGGL(k_ppo_step, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, a);

@@ -39,4 +39,4 @@ if f:
     nm = ["loads", "fwd L0", "fwd L1", "fwd L2", "fwd L3", "head", "bwd L3 park+dX", "bwd L3 barrier+dW", "bwd L2 park+dX", "bwd L2 barrier+dW", "bwd L1 park+dX",
           "bwd L1 barrier+dW", "bwd L0 park", "bwd L0 barrier+dW (to 13)", "epilogue", "pass loop top"]
     for k in range(16):
-        print(f"{k:2d} {nm[k]:28s} {out[k] / K / 256:10.0f} ticks per workgroup-launch {100.0 * out[k] / tot:5.1f} %")
+        print(f"{k:2d} {nm[k]:28s} {out[k] / K / 512:10.0f} ticks per workgroup-launch (wave 0 of the 512 workgroups: actor and critic blocks together) {100.0 * out[k] / tot:5.1f} %")
