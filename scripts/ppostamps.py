@@ -30,6 +30,10 @@ e0.record()
 for _ in range(K): fu.minibatch(obs, act, tv, adv, ret, lp, mu, sg, hp, phase=1)
 e1.record(); torch.cuda.synchronize()
 print(f"fwdbwd + reduce: {e0.elapsed_time(e1) / K * 1000:.1f} us per mini-batch of {B}")
+e0.record()
+for _ in range(K): fu.minibatch(obs, act, tv, adv, ret, lp, mu, sg, hp, phase=0)
+e1.record(); torch.cuda.synchronize()
+print(f"fwdbwd + step (the whole mini-batch): {e0.elapsed_time(e1) / K * 1000:.1f} us per mini-batch of {B}")
 if f:
     f(out, 0)
     names = ["loads", "fwd L0", "fwd L1", "fwd L2", "fwd L3", "head", "bwd L3 park+dX", "bwd L3 barrier+dW", "bwd L2 park+dX", "bwd L2 barrier+dW",
