@@ -125,11 +125,21 @@ template <class S>
 __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__ wp, const float* __restrict__ bp, const float* __restrict__ stdv,
                                             const float* obs, int N, int wave, uint64_t seed, uint64_t ctr, const ActOut& o) {
   constexpr int NL = S::NL, NF = S::nfrag(), I = S::I, AO = S::AO;
+  // Inside the rollout kernel the pointers come out of an LDS copy of the launch arguments: the compiler no longer knows that they are
+  // global memory and would emit flat_load / flat_store - which count on vmcnt AND lgkmcnt, out of order against LDS traffic, so every
+  // wait for a weight fragment became vmcnt(0) lgkmcnt(0): the ring was drained at each use. With the address space stated the ring
+  // is waited for with counted vmcnt, and a scheduling barrier after every request keeps the requests at their places in the MFMA
+  // stream (the scheduler otherwise moves them into clusters - same finding as in k_ppo_fwdbwd_split).
+  typedef const __attribute__((address_space(1))) f32x4* gf4p;
+  typedef const __attribute__((address_space(1))) float* gfp;
+  typedef __attribute__((address_space(1))) float* gwp;
+  const gf4p wg = (gf4p)wp;
+  const gfp bg = (gfp)bp, sg = (gfp)stdv, og = (gfp)obs;
   const int lane = threadIdx.x & 63, blk = lane >> 2, col = lane & 3, envl = col & 1;
   const int env = min(wave * 2 + envl, N - 1);
   const bool live = col < 2 && wave * 2 + envl < N;
   f32x4 ring[kRing];
-  sfor<kRing>([&](auto i) { ring[i] = wp[(size_t)(i < NF ? (int)i : 0) * 64 + lane]; });
+  sfor<kRing>([&](auto i) { ring[i] = wg[(size_t)(i < NF ? (int)i : 0) * 64 + lane]; __builtin_amdgcn_sched_barrier(0); });
   // ---- observation rows -> LDS (row 0), zero padded to the next k quad
   {
     const int e0 = min(wave * 2, N - 1), e1 = min(wave * 2 + 1, N - 1);
@@ -138,9 +148,9 @@ __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__
       const int idx = lane + 64 * i;
       if (idx < 2 * I) {
         const int e = idx >= I, k = idx - e * I;
-        const float v = obs[(size_t)(e ? e1 : e0) * I + k];
+        const float v = og[(size_t)(e ? e1 : e0) * I + k];
         xb[e * kXW + k] = v;
-        if (o.obs_store && wave * 2 + e < N) o.obs_store[(size_t)(wave * 2 + e) * I + k] = v;
+        if (o.obs_store && wave * 2 + e < N) ((gwp)o.obs_store)[(size_t)(wave * 2 + e) * I + k] = v;
       }
     }
     if (lane < 2 * (S::up4(I) - I)) xb[(lane & 1) * kXW + I + (lane >> 1)] = 0.0f;
@@ -157,7 +167,7 @@ __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__
     sfor<ng>([&](auto G) {
       constexpr int g = G;
       const int o0 = 4 * (16 * g + blk);                                     // first neuron of this lane's block
-      acc[g] = *reinterpret_cast<const f32x4*>(bp + S::boff(l) + g * 64 + blk * 4);
+      acc[g] = *reinterpret_cast<gf4p>(bg + S::boff(l) + g * 64 + blk * 4);
       xl[g] = xin + ((l > 0 && o0 >= oa4) ? 64 : 0);                          // critic blocks read the critic's activations
     });
     sfor<kq>([&](auto Q) {
@@ -165,7 +175,7 @@ __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__
       sfor<ng>([&](auto G) {
         constexpr int g = G, f = S::foff(l) + q * ng + g;
         const f32x4 w = ring[f % kRing];
-        if constexpr (f + kRing < NF) ring[f % kRing] = wp[(size_t)(f + kRing) * 64 + lane];
+        if constexpr (f + kRing < NF) { ring[f % kRing] = wg[(size_t)(f + kRing) * 64 + lane]; __builtin_amdgcn_sched_barrier(0); }
         const f32x4 x = *reinterpret_cast<const f32x4*>(xl[g] + 4 * q);
 #pragma unroll
         for (int kk = 0; kk < 4; kk++) acc[g] = __builtin_amdgcn_mfma_f32_4x4x1f32(w[kk], x[kk], acc[g], 0, 0, 0);
@@ -201,22 +211,23 @@ __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__
         f32x2u a2, m2, s2;
 #pragma unroll
         for (int hh = 0; hh < 2; hh++) {
-          const float m = out[2 * pr + hh], sd = stdv[f0 + hh];
+          const float m = out[2 * pr + hh], sd = sg[f0 + hh];
           a2[hh] = m + sd * z[hh]; m2[hh] = m; s2[hh] = sd;
           lp += -0.5f * z[hh] * z[hh] - __logf(sd) - 0.9189385332046727f;
         }
         if (live) {
-          *reinterpret_cast<f32x2u*>(o.actions + (size_t)env * AO + f0) = a2;
-          *reinterpret_cast<f32x2u*>(o.mu + (size_t)env * AO + f0) = m2;
-          *reinterpret_cast<f32x2u*>(o.sigma + (size_t)env * AO + f0) = s2;
+          typedef __attribute__((address_space(1))) f32x2u* g2p;
+          *(g2p)((gwp)o.actions + (size_t)env * AO + f0) = a2;
+          *(g2p)((gwp)o.mu + (size_t)env * AO + f0) = m2;
+          *(g2p)((gwp)o.sigma + (size_t)env * AO + f0) = s2;
         }
       }
     }
   } else if (blk == nab && live) {
-    o.values[env] = out[0];
+    ((gwp)o.values)[env] = out[0];
   }
   lp += __shfl_xor(lp, 4); lp += __shfl_xor(lp, 8); lp += __shfl_xor(lp, 16);     // over the action blocks (lane bits 2..4; blocks >= nab hold 0)
-  if (blk == 0 && live) o.logp[env] = lp;
+  if (blk == 0 && live) ((gwp)o.logp)[env] = lp;
 }
 
 // ---- the K-step launch (kernels in nm_rollout.hip - a translation unit of its own, so that the code generation of k_env_step in

@@ -26,7 +26,9 @@ namespace nmr {
 struct RecordRegs { float rw, to, cr, cl; long long d; };
 __device__ __forceinline__ void record_load(RecordRegs& r, const RollArgs* Rs, const nm::Args<float>* As, int wave) {
   const int lane = threadIdx.x, e = min(wave * 2 + (lane & 1), As->N - 1);
-  r.rw = As->rew[e]; r.d = As->done[e]; r.to = As->timeout_now[e]; r.cr = Rs->cur_ret[e]; r.cl = Rs->cur_len[e];
+  // (global-memory accessors of simt.h: the pointers come out of LDS copies of the arguments - plain dereferences would be flat_load)
+  r.rw = simt::gld1(As->rew, e); r.d = simt::gld1(As->done, e); r.to = simt::gld1(As->timeout_now, e);
+  r.cr = simt::gld1((const float*)Rs->cur_ret, e); r.cl = simt::gld1((const float*)Rs->cur_len, e);
 }
 __device__ __forceinline__ void record_file(const RecordRegs& r, const RollArgs* Rs, const nm::Args<float>* As, int t, int wave) {
   const int lane = threadIdx.x, N = As->N, e = wave * 2 + lane;
@@ -34,11 +36,11 @@ __device__ __forceinline__ void record_file(const RecordRegs& r, const RollArgs*
     const size_t so = (size_t)t * N;
     const bool d = r.d > 0;
     float cr = r.cr + r.rw, cl = r.cl + 1.0f;
-    Rs->s_rewards[so + e] = r.rw;
-    Rs->s_dones[so + e] = d ? 1 : 0;
+    simt::gst1(Rs->s_rewards, so + e, r.rw);
+    simt::gst1(Rs->s_dones, so + e, (unsigned char)(d ? 1 : 0));
     if (d) { atomicAdd(Rs->fin3, cr); atomicAdd(Rs->fin3 + 1, cl); atomicAdd(Rs->fin3 + 2, 1.0f); cr = 0.f; cl = 0.f; }
-    Rs->cur_ret[e] = cr; Rs->cur_len[e] = cl;
-    if (r.to != 0.f) Rs->to_step[e] = t;
+    simt::gst1(Rs->cur_ret, (size_t)e, cr); simt::gst1(Rs->cur_len, (size_t)e, cl);
+    if (r.to != 0.f) simt::gst1(Rs->to_step, (size_t)e, t);
   }
 }
 // The record of step t - 1 (t > 0) and PPO.act of step t for the wave's envs + the launch arguments of the env step that follows.
@@ -52,7 +54,7 @@ __device__ __noinline__ void policy_step(float* xb, const RollArgs* Rs, nm::Args
   if (t > 0) record_load(rec, Rs, As, wave);         // issued before the observation loads below: they return together
   ActOut o{Rs->s_actions + so * nm::kNU, Rs->s_logp + so, Rs->s_values + so, Rs->s_mu + so * nm::kNU, Rs->s_sigma + so * nm::kNU, t == 0 ? Rs->s_obs : nullptr};
   // the observation is the one this wave's previous step wrote into the storage row of step t
-  policy_wave<S>(xb, Rs->wp, Rs->bp, Rs->stdv, t == 0 ? Rs->obs0 : Rs->s_obs + so * nm::kNOBS, N, wave, Rs->seed, (uint64_t)Rs->iter_dev[0] * 4096ull + (uint64_t)t, o);
+  policy_wave<S>(xb, Rs->wp, Rs->bp, Rs->stdv, t == 0 ? Rs->obs0 : Rs->s_obs + so * nm::kNOBS, N, wave, Rs->seed, (uint64_t)simt::gld1(Rs->iter_dev, 0) * 4096ull + (uint64_t)t, o);
   if (t > 0) record_file(rec, Rs, As, t - 1, wave);
   if (threadIdx.x == 0) {
     As->actions = o.actions;
