@@ -503,8 +503,9 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
   auto wfrag = [&](auto FWD, auto IDX) -> f32x4 {
     constexpr bool fwd = FWD;
     constexpr int i = IDX;
-#if NM_PPO_ABL & 1      // measurement only: no weight stream (wrong results)
-    return f32x4{__int_as_float(wlane), 1.0f, 0.5f, 0.25f};
+#if NM_PPO_ABL & 1      // measurement only: no weight stream (wrong results). A different constant per fragment: with ONE constant the two
+                        // output tiles of a pair are the same chain and the compiler drops one of them (260 MFMAs instead of 432)
+    return f32x4{__int_as_float(wlane + 64 * i), 1.0f + i, 0.5f + i, 0.25f + i};
 #else
     return (fwd ? WF : WB)[i * 64 + wlane];
 #endif

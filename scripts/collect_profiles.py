@@ -7,7 +7,8 @@ G, P = os.path.join(ROOT, "gpurun_out"), os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 for name in ("bench.json.log", "bench_kernel_stats.csv", "train_kernel_stats.csv", "mlp_kernel_stats.csv", "pmc_step_summary.txt", "pmc_mlp_summary.txt",
              "curve_vs_cpu.json", "curve.log", "train40.log", "play.log", "parity_report.txt", "wavetimes.txt", "stage_stamps.txt", "rolloutbench.txt", "rolloutwaves.txt",
-             "pmc_lanes_summary.txt", "pmc_lanes.json", "bench_driverargs.json.log"):
+             "pmc_lanes_summary.txt", "pmc_lanes.json", "bench_driverargs.json.log", "ppobench.txt", "ppo_stage_stamps.txt", "pmc_ppo_summary.txt",
+             "pmc_ppo_mem_summary.txt"):
     src = os.path.join(G, f"{tag}_{name}")
     if os.path.exists(src):
         shutil.copy(src, os.path.join(P, f"{tag}_{name}"))

@@ -9,6 +9,7 @@ mkdir -p $OUT
 cd $ROOT
 if [ "$PART" != "b" ]; then
 echo "== bench"; python bench.py > $OUT/${TAG}_bench.json.log 2>&1; tail -c 600 $OUT/${TAG}_bench.json.log; echo
+python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_driverargs.json.log 2>&1
 echo "== train 40 iterations + play"; rm -rf logs; python train.py -e 4096 --iters 40 > $OUT/${TAG}_train40.log 2>&1; grep -E "^it +(1|20|39)/" $OUT/${TAG}_train40.log
 python scripts/play.py --log-root logs/nightmare_v3 -e 64 --steps 400 > $OUT/${TAG}_play.log 2>&1; tail -4 $OUT/${TAG}_play.log
 echo "== curves (HIP side; the CPU side of the same size: profiles/r04_curve_cpu_runs.json, tests/tools/curve_vs_cpu.py --kinds cpu in the build container)"
@@ -22,6 +23,11 @@ echo "== rocprof kernel stats + MFMA counters: mlp"; rocprofv3 --kernel-trace --
 rocprofv3 --kernel-trace --output-format csv --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA SQ_WAIT_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE -d $OUT/${TAG}_pmc_mlp -o run -- python3 $ROOT/scripts/mlpbench.py 4096 big > $OUT/${TAG}_pmc_mlp.log 2>&1
 for d in bench train mlp; do f=$(ls $OUT/${TAG}_prof_$d/*kernel_stats.csv $OUT/${TAG}_prof_$d/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $OUT/${TAG}_${d}_kernel_stats.csv && head -6 $OUT/${TAG}_${d}_kernel_stats.csv | cut -c1-200; done
 python $ROOT/scripts/pmc_summary.py $OUT/${TAG}_pmc_mlp k_mlp_fused > $OUT/${TAG}_pmc_mlp_summary.txt 2>&1; cat $OUT/${TAG}_pmc_mlp_summary.txt | head -12
+echo "== PPO forward / backward kernel: timing, SQ counters, memory-side counters"
+cd $ROOT; python scripts/ppostamps.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_ppobench.txt; cat $OUT/${TAG}_ppobench.txt
+[ -f nightmare_rl_amd/csrc/libnightmare_hip_ppostamps.so ] && NM_HIP_LIB=nightmare_rl_amd/csrc/libnightmare_hip_ppostamps.so python scripts/ppostamps.py 2>&1 | grep -v amdgpu > $OUT/${TAG}_ppo_stage_stamps.txt
+bash scripts/pmc_ppo.sh ${TAG} > $OUT/${TAG}_pmc_ppo_summary.txt 2>&1; tail -4 $OUT/${TAG}_pmc_ppo_summary.txt
+bash scripts/pmc_ppo_mem.sh ${TAG} > $OUT/${TAG}_pmc_ppo_mem_summary.txt 2>&1; tail -3 $OUT/${TAG}_pmc_ppo_mem_summary.txt
 fi
 if [ "$PART" != "a" ]; then
 cd /tmp && export TMPDIR=/tmp
