@@ -415,9 +415,6 @@ constexpr int kSplitWaves = 4, kSplitSlots = 16;
 #ifndef NM_PPO_SRING
 #define NM_PPO_SRING 10      // weight fragments in flight per wave (6 .. 14 measure the same)
 #endif
-#ifndef NM_PPO_DEFER
-#define NM_PPO_DEFER 1
-#endif
 #ifndef NM_PPO_ABL           // measurement builds only (wrong results): 1 no weight stream, 2 no dW, 4 no parking
 #define NM_PPO_ABL 0
 #endif
@@ -523,42 +520,14 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
     f32x4 a[NL][MT], d[2][MT], out[PO];
     sfor<T0>([&](auto T) { a[0][T] = live ? nx.obs[T] : f32x4{0, 0, 0, 0}; });
     PPO_STAMP(0);
-    // ---- forward. The epilogue of a pair of output tiles (ELU of 8 values per lane, which has to wait for the pair's last MFMA) is
-    // DEFERRED (NM_PPO_DEFER): it is issued behind the first k step of the NEXT pair's MFMAs - of the same layer or, for a layer's last
-    // pair, of the next layer's first pair, whose first k step reads tile 0 only - so the wave's MFMA stream does not stop at the eleven
-    // pair ends and most layer boundaries of a pass. A layer with a single pair (its tile 0 is needed at once) and the last layer drain.
-    f32x4 pa0 = {0, 0, 0, 0}, pa1 = {0, 0, 0, 0};      // the pair whose epilogue is pending
-    auto fwd_finish = [&](auto LYR, auto TO, const f32x4& acc) {
-      constexpr int l = LYR, to = TO;
-      if constexpr (l == NL - 1) {
-        out[to] = acc;
-      } else {
-        constexpr int NO = X::in(l + 1);      // real outputs of this layer = real inputs of the next (both nets)
-#pragma unroll
-        for (int reg = 0; reg < 4; reg++) {
-          const float v = acc[reg];
-          const float e = __expf(v) - 1.0f, y = v > 0.0f ? v : e;
-          if constexpr (16 * to + 16 <= NO) {
-            a[l + 1][to][reg] = y;
-          } else {
-            const int col = 16 * to + 4 * q + reg;
-            const float pad = col == NO ? 1.0f : 0.0f;
-            a[l + 1][to][reg] = col < NO ? y : pad;   // ELU | bias carrier | padding
-          }
-        }
-      }
-    };
-    auto fwd_flush = [&](auto LYR, auto PP) {      // the epilogue of pair PP of layer LYR, from pa0 / pa1
-      constexpr int l = LYR, to0 = 2 * PP, to1 = to0 + 1;
-      fwd_finish(std::integral_constant<int, l>{}, std::integral_constant<int, to0>{}, pa0);
-      if constexpr (to1 < X::nto(l)) fwd_finish(std::integral_constant<int, l>{}, std::integral_constant<int, to1 < X::nto(l) ? to1 : to0>{}, pa1);
-    };
+    // ---- forward
     sfor<NL>([&](auto L) {
-      constexpr int l = L, nkt = X::nkt(l), nto = X::nto(l), npair = (nto + 1) / 2;
+      constexpr int l = L, nkt = X::nkt(l), nto = X::nto(l);
+      constexpr bool last = l == NL - 1;
       if constexpr (l > 0) PPO_STAMP(l);
       if constexpr (l == LH) load_head(pass, cu);
-      sfor<npair>([&](auto PP) {
-        constexpr int pp = PP, to0 = 2 * pp, to1 = to0 + 1;
+      sfor<(nto + 1) / 2>([&](auto PP) {
+        constexpr int to0 = 2 * PP, to1 = to0 + 1;
         f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
         sfor<nkt>([&](auto TK) {
           constexpr int tk = TK;
@@ -578,16 +547,29 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
             acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], a[l][tk][j], acc0, 0, 0, 0);
             if constexpr (to1 < nto) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], a[l][tk][j], acc1, 0, 0, 0);
           }
-          if constexpr (NM_PPO_DEFER && tk == 0) {       // behind this pair's first k step: the pending epilogue
-            if constexpr (pp > 0) fwd_flush(std::integral_constant<int, l>{}, std::integral_constant<int, (pp > 0 ? pp - 1 : 0)>{});
-            else if constexpr (l > 0 && (X::nto(l > 0 ? l - 1 : 0) + 1) / 2 > 1)
-              fwd_flush(std::integral_constant<int, (l > 0 ? l - 1 : 0)>{}, std::integral_constant<int, (X::nto(l > 0 ? l - 1 : 0) + 1) / 2 - 1>{});
-          }
         });
-        pa0 = acc0; pa1 = acc1;
-        // drain: no deferral, the last layer, or a single-pair layer (the next layer's first k step needs its tile 0)
-        if constexpr (!NM_PPO_DEFER || l == NL - 1 || npair == 1) fwd_flush(std::integral_constant<int, l>{}, std::integral_constant<int, pp>{});
-        else if constexpr (pp + 1 == npair) { /* flushed by the next layer's first pair */ }
+        auto finish = [&](auto TO, const f32x4& acc) {
+          constexpr int to = TO;
+          if constexpr (last) {
+            out[to] = acc;
+          } else {
+            constexpr int NO = X::in(l + 1);      // real outputs of this layer = real inputs of the next (both nets)
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+              const float v = acc[reg];
+              const float e = __expf(v) - 1.0f, y = v > 0.0f ? v : e;
+              if constexpr (16 * to + 16 <= NO) {
+                a[l + 1][to][reg] = y;
+              } else {
+                const int col = 16 * to + 4 * q + reg;
+                const float pad = col == NO ? 1.0f : 0.0f;
+                a[l + 1][to][reg] = col < NO ? y : pad;   // ELU | bias carrier | padding
+              }
+            }
+          }
+        };
+        finish(std::integral_constant<int, to0>{}, acc0);
+        if constexpr (to1 < nto) finish(std::integral_constant<int, to1>{}, acc1);
       });
     });
     PPO_STAMP(4);
@@ -657,68 +639,39 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
     // the dX fragments are requested only now: in flight across the loss head they are 4 x kR registers that the head's divisions and
     // logarithms have no room for (the spill reloads each waited for the whole ring)
     sfor<kR>([&](auto i) { ring[i] = wfrag(std::false_type{}, i); NM_PPO_PIN(); });
-    // ---- backward. The epilogue of a pair of dX tiles (ELU' and the column mask) is deferred like the forward pass's: behind the first
-    // step of the next pair, and for a layer's last pair behind the first step of the NEXT layer's dX (or to the head of layer 0's block) -
-    // the parking of that layer's delta tiles follows it there.
-    f32x4 pb0 = {0, 0, 0, 0}, pb1 = {0, 0, 0, 0};
-    auto dx_finish = [&](auto LYR, auto NXT, auto TK, const f32x4& acc) {
-      constexpr int l = LYR, nxt = NXT, tk = TK;
-#pragma unroll
-      for (int reg = 0; reg < 4; reg++) {
-        const float av = a[l][tk][reg];
-        const float gr = acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f);                        // ELU'(z) from ELU(z)
-        if constexpr (16 * tk + 16 <= X::in(l)) d[nxt][tk][reg] = gr;
-        else d[nxt][tk][reg] = 16 * tk + 4 * q + reg < X::in(l) ? gr : 0.0f;              // no gradient into the 1-column / padding
-      }
-    };
-    auto dx_flush = [&](auto LYR, auto NXT, auto PP) {      // the epilogue of pair PP of dX of layer LYR (into d[NXT]), from pb0 / pb1
-      constexpr int l = LYR, tk0 = 2 * PP, tk1 = tk0 + 1;
-      dx_finish(LYR, NXT, std::integral_constant<int, tk0>{}, pb0);
-      if constexpr (tk1 < X::nkt(l)) dx_finish(LYR, NXT, std::integral_constant<int, (tk1 < X::nkt(l) ? tk1 : tk0)>{}, pb1);
-    };
+    // ---- backward
     sfor<NL>([&](auto LL) {
       constexpr int l = NL - 1 - LL, cur = LL & 1, nxt = cur ^ 1;
       constexpr int nkt = X::nkt(l), nto = X::nto(l);
-      constexpr int npb = (nkt + 1) / 2;                                              // pairs of this layer's dX
-      constexpr int npb_up = l + 1 < NL ? (X::nkt(l + 1 < NL ? l + 1 : l) + 1) / 2 : 1;   // ... of the layer above
-      constexpr bool pend_in = NM_PPO_DEFER && l + 1 < NL && npb_up > 1;             // a pair of the layer above is pending on entry
       // layout of the layer's exchange buffer: [delta tiles][row group] then [input tiles][row group]
       float* xb = (l & 1) ? xb1 : xb0;
       constexpr int dbase = 0, abase = nto;
       if constexpr (LL > 0) PPO_STAMP(5 + 2 * LL);
       // park this wave's deltas and layer inputs, transposed, for the workgroup's dW
-      auto park_d = [&]() {
 #if NM_PPO_ABL & 4      // measurement only: no parking
-        if (bt.B < 0)
+      if (bt.B < 0)
 #endif
-        sfor<nto>([&](auto T) {
-          constexpr int t = T;
+      {
+      sfor<nto>([&](auto T) {
+        constexpr int t = T;
 #pragma unroll
-          for (int reg = 0; reg < 4; reg++) xb[((dbase + t) * NG + g) * kTileF + (4 * q + reg) * kXT + prow] = d[cur][t][reg];
-        });
-      };
+        for (int reg = 0; reg < 4; reg++) xb[((dbase + t) * NG + g) * kTileF + (4 * q + reg) * kXT + prow] = d[cur][t][reg];
+      });
       if constexpr (l == 0) {       // the observation tile is not kept across the pass (20 registers): read it again (L2) for layer 0's dW
         RowData ob;
         load_rows(pass, ob);
         sfor<T0>([&](auto T) { a[0][T] = live ? ob.obs[T] : f32x4{0, 0, 0, 0}; });
       }
-#if NM_PPO_ABL & 4
-      if (bt.B < 0)
-#endif
       sfor<nkt>([&](auto T) {
         constexpr int t = T;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) xb[((abase + t) * NG + g) * kTileF + (4 * q + reg) * kXT + prow] = a[l][t][reg];
       });
-      if constexpr (!pend_in) park_d();
-      if constexpr (pend_in && l == 0) {
-        dx_flush(std::integral_constant<int, (l + 1 < NL ? l + 1 : l)>{}, std::integral_constant<int, cur>{}, std::integral_constant<int, npb_up - 1>{});
-        park_d();
       }
       // d_{l-1} = (W' d_l) * ELU'(a_l): registers only
       if constexpr (l > 0) {
-        sfor<npb>([&](auto PP) {
-          constexpr int pp = PP, tk0 = 2 * pp, tk1 = tk0 + 1;
+        sfor<(nkt + 1) / 2>([&](auto PP) {
+          constexpr int tk0 = 2 * PP, tk1 = tk0 + 1;
           f32x4 acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
           sfor<nto>([&](auto TO) {
             constexpr int to = TO;
@@ -738,18 +691,19 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
               acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(w0[j], d[cur][to][j], acc0, 0, 0, 0);
               if constexpr (tk1 < nkt) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(w1[j], d[cur][to][j], acc1, 0, 0, 0);
             }
-            if constexpr (NM_PPO_DEFER && to == 0) {       // behind this pair's first step: the pending epilogue
-              if constexpr (pp > 0) {
-                dx_flush(std::integral_constant<int, l>{}, std::integral_constant<int, nxt>{}, std::integral_constant<int, (pp > 0 ? pp - 1 : 0)>{});
-              } else if constexpr (pend_in) {
-                dx_flush(std::integral_constant<int, (l + 1 < NL ? l + 1 : l)>{}, std::integral_constant<int, cur>{}, std::integral_constant<int, npb_up - 1>{});
-                park_d();
-              }
-            }
           });
-          pb0 = acc0; pb1 = acc1;
-          // drain: no deferral, or a single-pair layer (the next layer's first step needs its tile 0); else the following pair / layer flushes
-          if constexpr (!NM_PPO_DEFER || npb == 1) dx_flush(std::integral_constant<int, l>{}, std::integral_constant<int, nxt>{}, std::integral_constant<int, pp>{});
+          auto finish = [&](auto TK, const f32x4& acc) {
+            constexpr int tk = TK;
+#pragma unroll
+            for (int reg = 0; reg < 4; reg++) {
+              const float av = a[l][tk][reg];
+              const float gr = acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f);                        // ELU'(z) from ELU(z)
+              if constexpr (16 * tk + 16 <= X::in(l)) d[nxt][tk][reg] = gr;
+              else d[nxt][tk][reg] = 16 * tk + 4 * q + reg < X::in(l) ? gr : 0.0f;              // no gradient into the 1-column / padding
+            }
+          };
+          finish(std::integral_constant<int, tk0>{}, acc0);
+          if constexpr (tk1 < nkt) finish(std::integral_constant<int, tk1>{}, acc1);
         });
       }
       if constexpr (l == 1) {
