@@ -557,7 +557,11 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
               const float v = acc[reg];
+#if NM_PPO_ABL & 16     // measurement only: no ELU
+              const float y = v;
+#else
               const float e = __expf(v) - 1.0f, y = v > 0.0f ? v : e;
+#endif
               if constexpr (16 * to + 16 <= NO) {
                 a[l + 1][to][reg] = y;
               } else {
@@ -576,6 +580,10 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
     // ---- loss head, by role. Actor: lane (row r, q) holds means 16 t + 4 q + reg, per-row sums cross the four q lanes. Critic: the
     // value is output column 0 (tile 0, register 0 of the q = 0 lanes).
     sfor<PO>([&](auto T) { d[0][T] = f32x4{0, 0, 0, 0}; });
+#if NM_PPO_ABL & 8      // measurement only: no loss head
+    sfor<PO>([&](auto T) { d[0][T] = out[T]; });
+    if (bt.B < 0)
+#endif
     if (!critic) {
       float lp = 0.0f, kl = 0.0f;
       float sd_[PO][4];
@@ -697,7 +705,11 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
 #pragma unroll
             for (int reg = 0; reg < 4; reg++) {
               const float av = a[l][tk][reg];
+#if NM_PPO_ABL & 16
+              const float gr = acc[reg] + av;
+#else
               const float gr = acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f);                        // ELU'(z) from ELU(z)
+#endif
               if constexpr (16 * tk + 16 <= X::in(l)) d[nxt][tk][reg] = gr;
               else d[nxt][tk][reg] = 16 * tk + 4 * q + reg < X::in(l) ? gr : 0.0f;              // no gradient into the 1-column / padding
             }
@@ -714,7 +726,9 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
         sfor<kR>([&](auto i) { ring[i] = wfrag(std::true_type{}, i); NM_PPO_PIN(); });
       }
       PPO_STAMP(6 + 2 * LL);
+#if !(NM_PPO_ABL & 32)  // measurement only: no barriers
       lds_barrier();
+#endif
 #if NM_PPO_ABL & 2      // measurement only: no dW
       if (bt.B < 0)
 #endif
