@@ -415,7 +415,7 @@ constexpr int kSplitWaves = 4, kSplitSlots = 16;
 #ifndef NM_PPO_SRING
 #define NM_PPO_SRING 10      // weight fragments in flight per wave (6 .. 14 measure the same)
 #endif
-#ifndef NM_PPO_ABL           // measurement builds only (wrong results): 1 no weight stream, 2 no dW, 4 no parking
+#ifndef NM_PPO_ABL           // measurement builds only (wrong results): 1 no weight stream, 2 no dW, 4 no parking, 8 no loss head, 16 no ELU, 32 no barriers
 #define NM_PPO_ABL 0
 #endif
 // The weight ring relies on vmcnt retiring in order: fragment i is waited for with vmcnt(number of fragments requested after it). The
@@ -459,37 +459,41 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
   // 28 registers that the compiler spills and reloads one by one, each reload behind a full vmcnt(0))
   struct RowData { f32x4 obs[T0]; };
   struct HeadData { f32x4 act[PO], omu[PO], osd[PO]; float adv, olp, ret, tv; };
-  auto row_of = [&](int pass) -> size_t {
+  // (row data is addressed as a uniform base + a 32-bit byte offset per lane - global_load with an SGPR base - instead of 64-bit
+  // per-lane pointers: every VALU instruction of a wave costs its full latency here, the MFMA stream does not hide it)
+  auto row_of = [&](int pass) -> unsigned {
     const int row = (pass * NG + g) * 16 + r;
-    return row < bt.B ? (bt.rows ? (size_t)bt.rows[row] : (size_t)row) : 0;
+    return row < bt.B ? (bt.rows ? (unsigned)bt.rows[row] : (unsigned)row) : 0u;
   };
+  auto ldf = [](const float* base, unsigned byte_off) -> float { return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off); };
   auto load_rows = [&](int pass, RowData& rd) {
-    const size_t lrow = row_of(pass);
+    const unsigned ob = row_of(pass) * (unsigned)(I * 4);
     sfor<T0>([&](auto T) {
       constexpr int t = T;
       if constexpr (16 * t + 16 <= I) {
-        rd.obs[t] = *reinterpret_cast<const f32x4u*>(bt.obs + lrow * I + 16 * t + 4 * q);
+        rd.obs[t] = *reinterpret_cast<const f32x4u*>(reinterpret_cast<const char*>(bt.obs) + (ob + 16u * q + 64u * t));
       } else {
 #pragma unroll
-        for (int reg = 0; reg < 4; reg++) { const int f = 16 * t + 4 * q + reg; const float v = bt.obs[lrow * I + (f < I ? f : 0)]; rd.obs[t][reg] = f < I ? v : (f == I ? 1.0f : 0.0f); }
+        for (int reg = 0; reg < 4; reg++) { const int f = 16 * t + 4 * q + reg; const float v = ldf(bt.obs, ob + 4u * (f < I ? f : 0)); rd.obs[t][reg] = f < I ? v : (f == I ? 1.0f : 0.0f); }
       }
     });
   };
   auto load_head = [&](int pass, HeadData& rd) {
-    const size_t lrow = row_of(pass);
+    const unsigned lrow = row_of(pass);
     if (!critic) {
+      const unsigned ab = lrow * (unsigned)(AO * 4);
       sfor<PO>([&](auto T) {
         constexpr int t = T;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
           const int f = 16 * t + 4 * q + reg;
-          const size_t at = lrow * AO + (f < AO ? f : 0);
-          rd.act[t][reg] = bt.actions[at]; rd.omu[t][reg] = bt.old_mu[at]; rd.osd[t][reg] = bt.old_sigma[at];
+          const unsigned at = ab + 4u * (f < AO ? f : 0);
+          rd.act[t][reg] = ldf(bt.actions, at); rd.omu[t][reg] = ldf(bt.old_mu, at); rd.osd[t][reg] = ldf(bt.old_sigma, at);
         }
       });
-      rd.adv = bt.adv[lrow]; rd.olp = bt.old_logp[lrow];
+      rd.adv = ldf(bt.adv, 4u * lrow); rd.olp = ldf(bt.old_logp, 4u * lrow);
     } else {
-      rd.ret = bt.ret[lrow]; rd.tv = bt.tval[lrow];
+      rd.ret = ldf(bt.ret, 4u * lrow); rd.tv = ldf(bt.tval, 4u * lrow);
     }
   };
   // the first layer at whose start all forward fragments are in flight or consumed
@@ -498,7 +502,7 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
   f32x4 ring[kR];
   const f32x4* __restrict__ WF = net.sf[nt];
   const f32x4* __restrict__ WB = net.sb[nt];
-  unsigned wlane = lane;       // made opaque once per pass: the weight fragments are re-read from L2 every pass, not hoisted out of the loop
+  unsigned wlane = 16u * lane; // this lane's byte offset inside a fragment; made opaque once per pass: the weight fragments are re-read from L2 every pass, not hoisted out of the loop
   asm volatile("" : "+v"(wlane));
   auto wfrag = [&](auto FWD, auto IDX) -> f32x4 {
     constexpr bool fwd = FWD;
@@ -507,7 +511,8 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
                         // output tiles of a pair are the same chain and the compiler drops one of them (260 MFMAs instead of 432)
     return f32x4{__int_as_float(wlane + 64 * i), 1.0f + i, 0.5f + i, 0.25f + i};
 #else
-    return (fwd ? WF : WB)[i * 64 + wlane];
+    // (a wave-uniform fragment base + a 32-bit byte offset per lane: global_load with an SGPR base, no 64-bit address arithmetic per load)
+    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>((fwd ? WF : WB) + i * 64) + wlane);
 #endif
   };
   if (vb < npass) load_rows(vb, nx);
@@ -560,7 +565,8 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
 #if NM_PPO_ABL & 16     // measurement only: no ELU
               const float y = v;
 #else
-              const float e = __expf(v) - 1.0f, y = v > 0.0f ? v : e;
+              // ELU(v) = v > 0 ? v : e with e = exp(v) - 1 >= v for every v: the median of (v, e, 0) - one v_med3_f32 instead of compare + select
+              const float e = __expf(v) - 1.0f, y = __builtin_amdgcn_fmed3f(v, e, 0.0f);
 #endif
               if constexpr (16 * to + 16 <= NO) {
                 a[l + 1][to][reg] = y;
@@ -585,20 +591,29 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
     if (bt.B < 0)
 #endif
     if (!critic) {
+      // Written on 1 / sigma and log sigma (one v_rcp_f32 and one v_log_f32 per column and pass, from an opaque copy of sigma: left to
+      // itself the compiler hoists every function of the loop-invariant sigmas out of the pass loop and spills them), so that a column
+      // costs ~25 VALU instructions instead of ~60 (the divisions' scaling sequences): with z = (a - mu) / sigma,
+      //   log p = -z^2 / 2 - log sigma - c,  d log p / d mu = z / sigma,  d log p / d sigma = (z^2 - 1) / sigma.
+      // On this chip the f32 MFMA does not hide a wave's own VALU work (scripts/micro/mfma_chain.hip: 4 dependent v_fma behind every MFMA
+      // cost their full 22 cycles on top of its 32), and the head runs on the actor blocks only: it is on the launch's critical path.
       float lp = 0.0f, kl = 0.0f;
-      float sd_[PO][4];
+      float is_[PO][4], zz[PO][4];
       sfor<PO>([&](auto T) {
         constexpr int t = T;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-          sd_[t][reg] = sdv[t][reg];
-          asm volatile("" : "+v"(sd_[t][reg]));      // (left to itself the compiler hoists every function of the loop-invariant sigmas out of the pass loop and spills them)
+          float sd = sdv[t][reg];
+          asm volatile("" : "+v"(sd));
           const int f = 16 * t + 4 * q + reg;
+          is_[t][reg] = 0.0f; zz[t][reg] = 0.0f;
           if (f < AO) {
-            const float mu = out[t][reg], sd = sd_[t][reg], osd = cu.osd[t][reg], omu = cu.omu[t][reg];
-            const float z = (cu.act[t][reg] - mu) / sd;
-            lp += -0.5f * z * z - __logf(sd) - 0.9189385332046727f;
-            kl += __logf(sd / osd + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) / (2.0f * sd * sd) - 0.5f;
+            const float is = __builtin_amdgcn_rcpf(sd), ls = __logf(sd);
+            const float mu = out[t][reg], osd = cu.osd[t][reg], omu = cu.omu[t][reg];
+            const float z = (cu.act[t][reg] - mu) * is;
+            lp += -0.5f * z * z - ls - 0.9189385332046727f;
+            kl += __logf(sd * __builtin_amdgcn_rcpf(osd) + 1.0e-5f) + (osd * osd + (omu - mu) * (omu - mu)) * (0.5f * is * is) - 0.5f;
+            is_[t][reg] = is; zz[t][reg] = z;
           }
         }
       });
@@ -614,16 +629,13 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
         a_kl += kl;
         if (q == 0) a_surr += fmaxf(s1, s2);
       }
-      sfor<PO>([&](auto T) {
+      sfor<PO>([&](auto T) {      // (dlogp = 0 on rows past the end of the mini-batch, is_ = z = 0 on columns past the actions: they add 0)
         constexpr int t = T;
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
-          const int f = 16 * t + 4 * q + reg;
-          if (live && f < AO) {
-            const float mu = out[t][reg], sd = sd_[t][reg], am = cu.act[t][reg] - mu;
-            d[0][t][reg] = dlogp * am / (sd * sd);
-            a_dstd[t][reg] += dlogp * (am * am / (sd * sd * sd) - 1.0f / sd);
-          }
+          const float gq = dlogp * is_[t][reg], z = zz[t][reg];
+          d[0][t][reg] = gq * z;
+          a_dstd[t][reg] += gq * (z * z - 1.0f);
         }
       });
     } else if (live && q == 0) {
@@ -708,7 +720,7 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
 #if NM_PPO_ABL & 16
               const float gr = acc[reg] + av;
 #else
-              const float gr = acc[reg] * (av > 0.0f ? 1.0f : av + 1.0f);                        // ELU'(z) from ELU(z)
+              const float gr = acc[reg] * fminf(av + 1.0f, 1.0f);                                // ELU'(z) from ELU(z): 1 if ELU > 0, else ELU + 1 (<= 1)
 #endif
               if constexpr (16 * tk + 16 <= X::in(l)) d[nxt][tk][reg] = gr;
               else d[nxt][tk][reg] = 16 * tk + 4 * q + reg < X::in(l) ? gr : 0.0f;              // no gradient into the 1-column / padding
