@@ -358,7 +358,7 @@ template <class S> struct Seq {
 };
 constexpr int kRing = 12;     // weight fragments in flight in k_ppo_act_fast
 
-// k_ppo_fwdbwd_split: the same mini-batch pass with TWO waves per SIMD. k_ppo_fwdbwd_fast keeps one 512-register wave per SIMD, so every
+// k_ppo_fwdbwd_split: the same mini-batch pass with TWO waves per SIMD. The merged kernel of rounds 2-3 kept one 512-register wave per SIMD, so every
 // stall of that wave - the ELU / loss-head VALU between MFMA chains, the LDS round trips of the dW operands, barriers, the weight ring's
 // L2 latency - is idle matrix-pipe time (measured: 50 % MFMA busy, 2x the MFMA floor). Giving each SIMD a second wave needs the per-wave
 // state to fit 256 registers; rows cannot be split further (an MFMA tile is 16 rows), but the NETWORK can: actor and critic are independent
@@ -816,7 +816,7 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
 }
 
 // ------------------------------------------------------------------------------------------------ collection step on the same packing
-// PPO.act for the reference-shaped network in ONE launch: the register-resident forward of k_ppo_fwdbwd_fast (one wave = 16 rows,
+// PPO.act for the reference-shaped network in ONE launch: the register-resident forward of the merged network (one wave = 16 rows,
 // weights from the update's own packed copy - no separate repack for the collector), then the sampling head on the output registers:
 // lane (row r, q) holds outputs 16 t + 4 q + reg, i.e. whole action pairs, so Box-Muller pairs, log-probability partials and the
 // storage writes need no exchange; the log-probability crosses the four q lanes with two shuffles. Same counter generator and keys
@@ -1476,7 +1476,7 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_minibatch: launch failed");
   return 0;
 }
-// does this network run on the compiled fast kernels (k_ppo_fwdbwd_fast, k_ppo_act_fast)?
+// does this network run on the compiled fast kernels (k_ppo_fwdbwd_split, k_ppo_act_fast)?
 extern "C" int32_t nm_ppo_has_fast_path(const nm_ppo* h) { return h && h->fast ? 1 : 0; }
 // PPO.act in one launch (fast-path networks only): forward of the merged network from the update's packed weights, sampling,
 // log-probability, value, and the rollout-storage writes of nm_ppo_sample (same generator and keys)
