@@ -222,6 +222,10 @@ int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream
 /* HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, grad norm;
  * reset_sums != 0 clears the two loss sums and the count afterwards. Synchronises the stream. */
 int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream);
+/* DEVICE out[9]: the same eight values and, [8], != 0 if the fused step's grid barrier timed out in the launches since the last read.
+ * Stream-ordered, no host synchronisation (rsl_rl's OnPolicyRunner.log reads its statistics after every update, caller reference
+ * train.py:54; the runner here reads this snapshot one iteration later, while the next rollout is already running). */
+int nm_ppo_snapshot_state(nm_ppo* h, float* out9_dev, int32_t reset_sums, void* stream);
 
 /* ---- The collection loop of rsl_rl v1.0.2 OnPolicyRunner.learn (`for i in range(num_steps_per_env): actions = alg.act(obs, critic_obs);
  * obs, _, rewards, dones, infos = env.step(actions); alg.process_env_step(rewards, dones, infos)`; caller reference train.py:54, horizon

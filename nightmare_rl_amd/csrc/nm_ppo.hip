@@ -1531,6 +1531,18 @@ extern "C" int nm_ppo_permutation(int32_t* out_dev, int32_t n, uint64_t seed, ui
 }
 // HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, gradient norm.
 // reset_sums != 0 clears the loss sums and the mini-batch count afterwards. Synchronises the stream.
+// the same nine values (out[8] != 0: k_ppo_step's grid barrier timed out) copied to DEVICE memory, stream-ordered and without a host
+// synchronisation: the caller reads them (e.g. through a pinned host copy) whenever it likes - the runner does so one iteration later, while
+// the next rollout is already running
+extern "C" int nm_ppo_snapshot_state(nm_ppo* h, float* out9_dev, int32_t reset_sums, void* stream) {
+  if (!h || !out9_dev) return nm_policy_set_error("nm_ppo_snapshot_state: bad argument");
+  PPO_CHK(hipSetDevice(h->device));
+  hipStream_t s = (hipStream_t)stream;
+  PPO_CHK(hipMemcpyAsync(out9_dev, h->state, 9 * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (reset_sums) PPO_CHK(hipMemsetAsync(h->state + 3, 0, 3 * sizeof(float), s));
+  PPO_CHK(hipMemsetAsync(h->state + 8, 0, sizeof(float), s));
+  return 0;
+}
 extern "C" int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream) {
   if (!h || !out8_host) return nm_policy_set_error("nm_ppo_get_state: bad argument");
   PPO_CHK(hipSetDevice(h->device));

@@ -301,6 +301,23 @@ class FusedUpdate:
         self.publish_step()
         return st
 
+    STATE_KEYS = ("lr", "steps", "kl", "value_loss_sum", "surrogate_loss_sum", "minibatches", "clip_coef", "grad_norm")
+
+    def snapshot_state(self, out9, reset_sums=True):
+        """The values of read_state() copied into the DEVICE tensor out9 (9 floats; [8] != 0: the fused step's grid barrier timed out),
+        stream-ordered and without a host synchronisation. The runner reads it one iteration later (state_from)."""
+        assert out9.is_cuda and out9.dtype == torch.float32 and out9.numel() >= 9 and out9.is_contiguous()
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        _lib.check(self._L.nm_ppo_snapshot_state(self._h, C.c_void_p(out9.data_ptr()), int(reset_sums), stream))
+
+    def state_from(self, vals9):
+        """dict like read_state() from the nine host floats of a snapshot."""
+        if vals9[8] != 0.0:
+            raise _lib.NightmareHipError("nm_ppo: the grid barrier of the fused mini-batch step timed out (GPU shared with another job?); set NM_PPO_UNFUSED_STEP=1")
+        st = dict(zip(self.STATE_KEYS, [float(x) for x in vals9[:8]]))
+        self.step_count = int(round(st["steps"]))
+        return st
+
     def publish_step(self):
         """Adam's step count into the torch optimizer's state (what a checkpoint saves next to the moments; rsl_rl saves
         optimizer.state_dict(), reference train.py:49-52 resumes from it)."""

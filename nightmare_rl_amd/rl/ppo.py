@@ -142,7 +142,7 @@ class PPO:
             g.copy_(flat[off:off + n].view_as(g))
             off += n
 
-    def _update_fused(self):
+    def _update_fused(self, defer=None):
         hp = dict(clip=self.clip_param, value_coef=self.value_loss_coef, entropy_coef=self.entropy_coef, clip_value=self.use_clipped_value_loss,
                   desired_kl=self.desired_kl if self.desired_kl is not None else 0.0,
                   adaptive=self.desired_kl is not None and self.schedule == "adaptive", max_grad_norm=self.max_grad_norm)
@@ -204,17 +204,30 @@ class PPO:
                     fu.minibatch_data_parallel(*batch, hp=hp, world=_world())
                 else:
                     fu.minibatch(*batch, hp)
+        if defer is not None:
+            # the caller reads the update's statistics later (runner: one iteration later, while the next rollout runs): no host
+            # synchronisation here. The learning rate, KL and Adam's step count that matter live on the device; apply_state() brings the
+            # host's copies (logging, checkpoints) up to date
+            fu.snapshot_state(defer)
+            self.reset_collection()
+            return None
         st = fu.read_state()                      # the one host synchronisation of the update
+        self.reset_collection()
+        return self.apply_state(st)
+
+    def apply_state(self, st):
+        """Host-side mirror of what the fused update left on the device (st: FusedUpdate.read_state() / state_from()); returns the
+        mean value and surrogate losses of the update like update() does."""
         self.learning_rate, self.last_kl = st["lr"], st["kl"]
         for g in self.optimizer.param_groups:
             g["lr"] = self.learning_rate
         n = max(st["minibatches"], 1.0)
-        self.reset_collection()
         return st["value_loss_sum"] / n, st["surrogate_loss_sum"] / n
 
-    def update(self):
+    def update(self, defer=None):
+        """rsl_rl PPO.update. defer (fused path only): a 9-float device tensor that receives the update's statistics instead of a host read."""
         if getattr(self, "fused_update", None) is not None:
-            return self._update_fused()
+            return self._update_fused(defer)
         v_sum = torch.zeros((), device=self.device)
         s_sum = torch.zeros((), device=self.device)
         gen = self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs)
