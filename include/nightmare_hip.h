@@ -155,6 +155,12 @@ int nm_policy_forward(nm_policy* h, const float* obs_dev, int32_t num_envs, floa
  * rewards/values/returns [T,N] f32, dones [T,N] u8, last_values [N] f32, all device memory. */
 int nm_gae(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev,
            int32_t T, int32_t N, float gamma, float lam, float* returns_dev, void* stream);
+/* The same plus the rest of RolloutStorage.compute_returns (rsl_rl v1.0.2 `storage/rollout_storage.py`; caller reference train.py:54):
+ * advantages[T,N] = returns - values and, normalize != 0, (advantages - mean) / (std + 1e-8) over all T x N entries (unbiased std) - two
+ * launches, reproducible summation order. scratch_dev: 2 * ceil(N / 256) floats. One GPU's envs only: a multi-rank job normalises over
+ * all ranks (normalize = 0 here, then the caller's all-reduced statistics). */
+int nm_gae_advantages(const float* rewards_dev, const float* values_dev, const unsigned char* dones_dev, const float* last_values_dev, int32_t T, int32_t N,
+                      float gamma, float lam, float* returns_dev, float* advantages_dev, float* scratch_dev, int32_t normalize, void* stream);
 
 /* Rollout collection of the on-policy loop (rsl_rl v1.0.2 PPO.act / PPO.process_env_step; caller reference train.py:54), one launch each.
  * nm_ppo_sample: net_out_dev [N, A+1] = action means | critic value (nm_policy_forward on the merged actor+critic network), std_dev [A];
@@ -252,6 +258,8 @@ typedef struct {
   float gamma;                         /* time-out bootstrap: rewards += gamma * value * extras['time_outs'] (PPO.process_env_step) */
   float *cur_ret, *cur_len, *fin3;     /* [N] [N] [3]: as nm_ppo_record */
   const int32_t* ep_idx_dev; int32_t n_ep; float* ep_acc_dev;   /* ep_acc[i] += extras['episode'][ep_idx[i]] after every step, i < n_ep <= NM_NUM_REWARDS */
+  float* last_values_dev;              /* [N] or NULL: the critic's value of the observation after the last step - rsl_rl PPO.compute_returns'
+                                          `last_values = actor_critic.evaluate(last_critic_obs)` - evaluated by the env's wave at the end of the launch */
 } nm_rollout_args;
 /* 1 if nm_rollout / nm_rollout_act are compiled for these networks (dims = {n_obs, h1, h2, h3, n_out}, HOST arrays) */
 int nm_rollout_supported(const int32_t* actor_dims, const int32_t* critic_dims, int32_t n_layers);

@@ -581,6 +581,7 @@ template <class real> struct Env : nm_env {
       R.s_obs = r->s_obs; R.s_actions = r->s_actions; R.s_logp = r->s_logp; R.s_values = r->s_values; R.s_mu = r->s_mu; R.s_sigma = r->s_sigma;
       R.s_rewards = r->s_rewards; R.s_dones = r->s_dones; R.cur_ret = r->cur_ret; R.cur_len = r->cur_len; R.fin3 = r->fin3;
       R.st_sum = roll_sum; R.st_cnt = roll_cnt; R.to_step = roll_to;
+      R.last_values = r->last_values_dev;
       R.wave_clock = A.dbg ? reinterpret_cast<unsigned long long*>(A.dbg) : nullptr;   // measurement: the debug buffer ([N,256] reals) takes the waves' clocks instead
       nmr::TailArgs ta{N, K, roll_sum, roll_cnt, roll_to, r->ep_stats_dev, r->time_outs_dev, M.ep_len_s, counters_dev, r->bootstrap_time_outs ? r->gamma : -1.0f, r->s_values, r->s_rewards,
                        r->ep_idx_dev, r->n_ep, r->ep_acc_dev, A.to_owner};

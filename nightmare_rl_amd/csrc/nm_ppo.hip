@@ -1220,6 +1220,7 @@ __global__ void k_ppo_perm(int* __restrict__ out, int n, int half, uint32_t k0, 
 // ------------------------------------------------------------------------------------------------ handle + C ABI
 struct nm_ppo {
   int device = 0, n_layers = 0, A = 0, nparam = 0, nwg = 0, wm_total = 0;
+  int nrows = 0;               // partial rows the last forward / backward launch wrote (<= nwg): what the reductions add up
   bool fast = false;           // the network has the shape k_ppo_fwdbwd_split / k_ppo_act_fast are compiled for
   float *sf = nullptr, *sb = nullptr;       // split kernel: both nets' forward / dX fragments (actor first)
   int *sfi = nullptr, *sbi = nullptr;       // per flat parameter: its float position in sf / sb (-1: none)
@@ -1452,15 +1453,17 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     PpoBatch bt{obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, flat_dev + (h->nparam - h->A), B, n_obs, clip, value_coef, 1.0f / (float)B, clip_value, rows_dev};
     const int rows = h->fast ? 16 * kSplitWaves : kRows;
     const int ntiles = (B + rows - 1) / rows, grid = ntiles < h->nwg ? ntiles : h->nwg;
-    if (grid < h->nwg) PPO_CHK(hipMemsetAsync(h->partial, 0, (size_t)h->nwg * stride * sizeof(float), s));
+    // the reductions add the `grid` rows this launch writes and no others (the rows beyond used to be cleared by a 28 MB memset per
+    // mini-batch; inside the update's captured graph that memset node corrupted the loss sums of small batches: grid < number of CUs)
+    h->nrows = grid;
     if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_split<RefShape>, dim3(2 * grid), dim3(64 * kSplitWaves), 0, s, h->net, bt, h->partial);      // two blocks (actor, critic) per partial row
     else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
     if (phase == 1 || !h->fused_step)
-      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nwg, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
+      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nrows, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
   }
   if ((phase == 0 || phase == 2) && h->fused_step) {     // reduce (phase 0) + scalars + Adam + both packings: one launch
     StepArgs a;
-    a.partial = h->partial; a.nwg = h->nwg; a.stride = stride; a.gtotal = h->net.gtotal; a.map = h->map; a.n = h->nparam;
+    a.partial = h->partial; a.nwg = h->nrows; a.stride = stride; a.gtotal = h->net.gtotal; a.map = h->map; a.n = h->nparam;
     a.flat = flat_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev; a.grad = h->grad; a.state = h->state; a.Wm = h->Wm; a.n2part = h->n2part;
     a.pf = reinterpret_cast<float*>(h->pf); a.pb = reinterpret_cast<float*>(h->pb); a.pfi = h->pfi; a.pbi = h->pbi; a.bar = h->bar;
     a.sf = h->sf; a.sb = h->sb; a.sfi = h->sfi; a.sbi = h->sbi;
@@ -1468,7 +1471,7 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adaptive = adaptive; a.kl_from_grad = phase == 2 ? 1 : 0; a.do_reduce = phase == 0 ? 1 : 0;
     hipLaunchKernelGGL(k_ppo_step, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, a);
   } else if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced gradient | KL; the KL is then read from there
-    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nwg, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,
+    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nrows, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,
                        adaptive, max_grad_norm, kl_override, phase == 2 ? 1 : 0, h->state);
     hipLaunchKernelGGL(k_ppo_adam, dim3(nb), dim3(256), 0, s, flat_dev, exp_avg_dev, exp_avg_sq_dev, h->grad, h->nparam, h->state, beta1, beta2, eps, h->map, h->Wm);
     if (ppo_pack(h, s)) return 1;

@@ -31,6 +31,64 @@ extern "C" int nm_gae(const float* rewards, const float* values, const unsigned 
   return 0;
 }
 
+// GAE + what RolloutStorage.compute_returns does next (rsl_rl v1.0.2: advantages = returns - values, then (adv - mean) / (std + 1e-8) over all
+// envs x steps, unbiased std) in two launches instead of ~18 framework launches whose host-side issue left the GPU idle for ~0.3 ms per
+// iteration: k_gae_adv walks its env like k_gae, writes returns and raw advantages and leaves per-block partial sums (sum, sum of
+// squares; fixed summation order: a thread adds its env's steps last-to-first, the block adds its threads by a fixed tree); k_adv_norm
+// adds the partials in block order in every block (same mean / std everywhere, reproducible) and normalises in place.
+constexpr int kGaeThreads = 256;
+__global__ void __launch_bounds__(kGaeThreads) k_gae_adv(const float* __restrict__ rewards, const float* __restrict__ values, const unsigned char* __restrict__ dones,
+                                                         const float* __restrict__ last_values, int T, int N, float gamma, float lam, float* __restrict__ returns,
+                                                         float* __restrict__ adv_out, float* __restrict__ partial) {
+  __shared__ float red[2][kGaeThreads];
+  const int e = blockIdx.x * kGaeThreads + threadIdx.x;
+  float s1 = 0.0f, s2 = 0.0f;
+  if (e < N) {
+    float adv = 0.0f, next = last_values[e];
+    for (int s = T - 1; s >= 0; s--) {
+      const size_t i = (size_t)s * N + e;
+      const float live = 1.0f - (float)dones[i];
+      const float v = values[i];
+      const float delta = rewards[i] + live * gamma * next - v;
+      adv = delta + live * gamma * lam * adv;
+      const float ret = adv + v;
+      returns[i] = ret;
+      const float a = ret - v;                  // torch.sub(returns, values): what the framework path stores (not `adv` itself)
+      adv_out[i] = a;
+      s1 += a; s2 += a * a;
+      next = v;
+    }
+  }
+  red[0][threadIdx.x] = s1; red[1][threadIdx.x] = s2;
+  __syncthreads();
+  for (int o = kGaeThreads / 2; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { red[0][threadIdx.x] += red[0][threadIdx.x + o]; red[1][threadIdx.x] += red[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { partial[2 * blockIdx.x] = red[0][0]; partial[2 * blockIdx.x + 1] = red[1][0]; }
+}
+__global__ void __launch_bounds__(256) k_adv_norm(float* __restrict__ adv, size_t n, const float* __restrict__ partial, int nblk) {
+  float s1 = 0.0f, s2 = 0.0f;
+  for (int b = 0; b < nblk; b++) { s1 += partial[2 * b]; s2 += partial[2 * b + 1]; }      // the same order in every thread
+  const float cnt = (float)n, mean = s1 / cnt;
+  const float var = fmaxf(s2 / cnt - mean * mean, 0.0f) * (cnt / fmaxf(cnt - 1.0f, 1.0f));   // unbiased, like torch.std (distributed.global_advantage_stats)
+  const float inv = 1.0f / (sqrtf(var) + 1e-8f);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) adv[i] = (adv[i] - mean) * inv;
+}
+extern "C" int nm_gae_advantages(const float* rewards, const float* values, const unsigned char* dones, const float* last_values, int32_t T, int32_t N,
+                                 float gamma, float lam, float* returns, float* advantages, float* scratch, int32_t normalize, void* stream) {
+  if (!rewards || !values || !dones || !last_values || !returns || !advantages || !scratch || T <= 0 || N <= 0) return nm_policy_set_error("nm_gae_advantages: bad argument");
+  const int nblk = (N + kGaeThreads - 1) / kGaeThreads;
+  hipLaunchKernelGGL(k_gae_adv, dim3(nblk), dim3(kGaeThreads), 0, (hipStream_t)stream, rewards, values, dones, last_values, T, N, gamma, lam, returns, advantages, scratch);
+  if (normalize) {
+    const size_t n = (size_t)T * N;
+    const int grid = (int)((n + 1023) / 1024 < 1024 ? (n + 1023) / 1024 : 1024);
+    hipLaunchKernelGGL(k_adv_norm, dim3(grid), dim3(256), 0, (hipStream_t)stream, advantages, n, scratch, nblk);
+  }
+  if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_gae_advantages: launch failed");
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ rollout collection
 // PPO.act of rsl_rl v1.0.2 (`algorithms/ppo.py`: actor mean, Normal(mean, std).sample(), log_prob, critic value, transition record)
 // after the fused actor+critic forward (nm_policy_forward on the merged network: out[N, A+1] = action means | value):

@@ -121,7 +121,8 @@ struct ActOut {
 
 // PPO.act for the wave's two envs (env = 2 wave + column). xb: kXFloats floats of the wave's LDS. obs: [N, I] device memory that this wave
 // may have written itself a moment ago (the caller has waited for those stores). `env_id0` = global id of env 0 (noise key).
-template <class S>
+// VALUE_ONLY: the same forward, but nothing is sampled or filed except the critic's value into o.values[env] (the last observation of a rollout).
+template <class S, bool VALUE_ONLY = false>
 __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__ wp, const float* __restrict__ bp, const float* __restrict__ stdv,
                                             const float* obs, int N, int wave, uint64_t seed, uint64_t ctr, const ActOut& o) {
   constexpr int NL = S::NL, NF = S::nfrag(), I = S::I, AO = S::AO;
@@ -198,6 +199,10 @@ __device__ __forceinline__ void policy_wave(float* xb, const f32x4* __restrict__
   // ---- sampling head on the output tile: lane (block b, column j) holds action means 4 b .. 4 b + 3 of env j (b < oa4 / 4) or the value (first critic block)
   constexpr int nab = S::oa4(NL - 1) / 4;
   float lp = 0.0f;
+  if constexpr (VALUE_ONLY) {
+    if (blk == nab && live) ((gwp)o.values)[env] = out[0];
+    return;
+  }
   if (blk < nab) {
 #pragma unroll
     for (int pr = 0; pr < 2; pr++) {
@@ -242,6 +247,7 @@ struct RollArgs {
   float *cur_ret, *cur_len, *fin3;                             // the runner's episode bookkeeping (nm_ppo_record's)
   float* st_sum; int* st_cnt;                                  // [K,kNREW], [K,4]: per-step accumulators (Args::stat_sum / stat_cnt of that step)
   int* to_step;                                                // [N]: the step at which the env timed out in this rollout, or -1
+  float* last_values;                                          // [N] or null: the critic's value of the observation after the last step (PPO.compute_returns)
   unsigned long long* wave_clock;                              // measurement (nm_set_debug_buffer on): [waves][2] s_memtime at the wave's start / end, else null
 };
 struct TailArgs {

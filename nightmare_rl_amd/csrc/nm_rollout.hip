@@ -73,6 +73,14 @@ __device__ __noinline__ void record_last(const RollArgs* Rs, const nm::Args<floa
   record_load(rec, Rs, As, wave);
   record_file(rec, Rs, As, t, wave);
 }
+// PPO.compute_returns' `last_values = actor_critic.evaluate(last_critic_obs)` for the wave's envs: the forward once more, on the observation the
+// last step left in obs_final (this wave's own stores: waited for by record_last), value head only - instead of nine framework launches
+template <class S>
+__device__ __noinline__ void value_last(float* xb, const RollArgs* Rs, const nm::Args<float>* As, int wave) {
+  ActOut o{nullptr, nullptr, Rs->last_values, nullptr, nullptr, nullptr};
+  nm::wave_sync();
+  policy_wave<S, true>(xb, Rs->wp, Rs->bp, Rs->stdv, Rs->obs_final, As->N, wave, 0, 0, o);
+}
 
 template <class S>
 __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_rollout(const nm::Model<float>* __restrict__ Mp, nm::Args<float> A, RollArgs R) {
@@ -109,6 +117,7 @@ __global__ void __launch_bounds__(64, NM_WAVES_PER_SIMD) k_env_rollout(const nm:
     nm::wave_step<float, 2>(sh, Ms, As, wave);        // env.step: load, decimation x mj_step, epilogue - the code of k_env_step
   }
   record_last(&Rs, &As, K - 1, wave);
+  if (Rs.last_values) value_last<S>(xb, &Rs, &As, wave);
   if (Rs.wave_clock && threadIdx.x == 0) Rs.wave_clock[2 * wave + 1] = __builtin_amdgcn_s_memtime();
 }
 // One env's policy step as a launch of its own: PPO.act on the same wave code (the step-by-step counterpart of k_env_rollout and its

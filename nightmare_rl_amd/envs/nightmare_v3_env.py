@@ -215,13 +215,14 @@ class NightmareV3Env:
         return self.obs_buf, None, self.rew_buf, self.reset_buf, self.extras
 
     # ------------------------------------------------------------------ K steps per launch with the policy in the env's wave
-    def policy_rollout(self, steps, params_flat, seed, iter_dev, storage, gamma, cur_ret, cur_len, fin, ep=None):
+    def policy_rollout(self, steps, params_flat, seed, iter_dev, storage, gamma, cur_ret, cur_len, fin, ep=None, last_values=None):
         """`steps` iterations of rsl_rl's collection loop `act -> env.step -> process_env_step` (OnPolicyRunner.learn; reference
         train.py:54) as ONE launch (nm_rollout): starts from the current observation, files every transition into `storage` (a
         RolloutStorage with `steps` rows: observations, actions, values, log-probabilities, mu, sigma, rewards incl. the time-out bootstrap,
         dones), updates the runner's bookkeeping tensors (cur_ret / cur_len [N], fin [3], and ep = (ep_idx int32, ep_acc) for the running
         sum of extras['episode']) and leaves the env as `steps` calls of step() would: obs_buf / rew_buf / reset_buf / extras of the last step.
-        params_flat: the flat parameter vector of FusedUpdate (actor W0 b0 ..., critic ..., std)."""
+        params_flat: the flat parameter vector of FusedUpdate (actor W0 b0 ..., critic ..., std). last_values ([N] float32 on the device,
+        optional) receives the critic's value of the last observation - what PPO.compute_returns evaluates next."""
         if self.cfg.viewer.record_states:
             raise ValueError("policy_rollout: cfg.viewer.record_states needs one launch per step")
         T = int(steps)
@@ -248,8 +249,9 @@ class NightmareV3Env:
         a.gamma = float(gamma)
         a.cur_ret, a.cur_len, a.fin3 = cur_ret.data_ptr(), cur_len.data_ptr(), fin.data_ptr()
         a.ep_idx_dev, a.n_ep, a.ep_acc_dev = (ep_idx.data_ptr(), int(ep_idx.numel()), ep_acc.data_ptr()) if ep_idx is not None else (None, 0, None)
+        a.last_values_dev = last_values.data_ptr() if last_values is not None else None
         self._ck(self._L.nm_rollout(self._h, C.byref(a), self._stream()))
-        self._keep_rollout = (params_flat, iter_dev, storage, cur_ret, cur_len, fin, ep_idx, ep_acc)
+        self._keep_rollout = (params_flat, iter_dev, storage, cur_ret, cur_len, fin, ep_idx, ep_acc, last_values)
         self.common_step_counter += T
         storage.step = T
         if "episode" not in self.extras:

@@ -32,6 +32,7 @@ class FusedCollector:
         return all(x.out_features + y.out_features <= 256 for x, y in zip(a, c)) and a[0].in_features <= 256
 
     def __init__(self, ac, num_envs, device, seed=0, update=None):
+        self.last_values = None          # set by rollout(): the critic's value of the rollout's last observation, for PPO.compute_returns
         """update: the FusedUpdate of the same networks, if there is one. When its handle has the compiled fast path, `act` is ONE
         launch (nm_ppo_act: forward from the update's own packed weights + sampling) and `refresh` has nothing to repack."""
         self.ac, self.device, self.N = ac, torch.device(device), int(num_envs)
@@ -133,12 +134,17 @@ class FusedCollector:
         Same noise keys as act(): (seed, iteration set by refresh(), step, env, action pair)."""
         self.drop_pending()
         storage.clear()
-        return env.policy_rollout(steps, self.update.flat, self.seed, self.iter_dev, storage, gamma, cur_ret, cur_len, fin, ep=ep)
+        if getattr(self, "_last_values", None) is None or self._last_values.numel() != env.num_envs:
+            self._last_values = torch.zeros(env.num_envs, device=self.device)
+        o = env.policy_rollout(steps, self.update.flat, self.seed, self.iter_dev, storage, gamma, cur_ret, cur_len, fin, ep=ep, last_values=self._last_values)
+        self.last_values = self._last_values      # the value of the observation after the last step: PPO.compute_returns takes it (once)
+        return o
 
     def drop_pending(self):
         """Forget a deferred record without launching it: the storage it would write into has been cleared (end of an update, a failed
         graph capture) - its arguments point at a step that no longer exists."""
         self._pending = None
+        self.last_values = None
 
     def flush(self):
         """Launch the bookkeeping of a step whose act() successor has not come (the last step of a rollout). A no-op otherwise."""

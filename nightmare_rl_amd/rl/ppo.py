@@ -126,7 +126,13 @@ class PPO:
 
     def compute_returns(self, last_critic_obs):
         self.end_rollout()
-        last_values = self.actor_critic.evaluate(last_critic_obs).detach()
+        lv = getattr(self.fused, "last_values", None) if getattr(self, "fused", None) is not None else None
+        if lv is not None:
+            # the one-launch rollout has evaluated the critic on its last observation already (nm_rollout_args.last_values_dev)
+            self.fused.last_values = None
+            last_values = lv.view(-1, 1)
+        else:
+            last_values = self.actor_critic.evaluate(last_critic_obs).detach()
         self.storage.compute_returns(last_values, self.gamma, self.lam)
 
     def _sync_grads(self):

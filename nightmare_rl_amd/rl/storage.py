@@ -4,6 +4,7 @@ GPU and in torch on the host (tests)."""
 import ctypes as C
 
 import torch
+import torch.distributed as dist
 
 from ..distributed import global_advantage_stats
 
@@ -55,7 +56,16 @@ class RolloutStorage:
             T, N = self.num_transitions_per_env, self.num_envs
             stream = C.c_void_p(torch.cuda.current_stream(self.rewards.device).cuda_stream)
             lv = last_values.contiguous().view(-1).float()
+            one = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
             with torch.cuda.device(self.rewards.device):
+                if one:
+                    # returns, advantages and their normalisation in two launches (nm_gae_advantages); with several ranks the
+                    # statistics are all-reduced below
+                    if getattr(self, "_gae_scratch", None) is None:
+                        self._gae_scratch = torch.zeros(2 * ((N + 255) // 256), device=self.rewards.device)
+                    _lib.check(L.nm_gae_advantages(self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(), lv.data_ptr(), T, N, float(gamma),
+                                                   float(lam), self.returns.data_ptr(), self.advantages.data_ptr(), self._gae_scratch.data_ptr(), 1, stream))
+                    return
                 _lib.check(L.nm_gae(self.rewards.data_ptr(), self.values.data_ptr(), self.dones.data_ptr(), lv.data_ptr(), T, N,
                                     float(gamma), float(lam), self.returns.data_ptr(), stream))
         else:

@@ -106,7 +106,8 @@ def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise
         ea, ba, sa = envs[0], book[0], sts[0]
         obs_before = ea.get_observations()
         keep = obs_before.clone()
-        oa = ea.policy_rollout(T, fu.flat, 99, it, sa, gamma, ba["cur_ret"], ba["cur_len"], ba["fin"], ep=(ep_idx, ba["ep_acc"]))
+        lv = torch.full((N,), float("nan"), device=DEV)
+        oa = ea.policy_rollout(T, fu.flat, 99, it, sa, gamma, ba["cur_ret"], ba["cur_len"], ba["fin"], ep=(ep_idx, ba["ep_acc"]), last_values=lv)
         assert torch.equal(obs_before, keep)                      # the tensor handed out before stays untouched (two observation buffers)
         # B: one launch per piece and step
         eb, bb, sb = envs[1], book[1], sts[1]
@@ -121,6 +122,13 @@ def test_one_launch_rollout_equals_the_step_by_step_path_bit_for_bit(N, T, noise
         for name in ("observations", "actions", "values", "actions_log_prob", "mu", "sigma", "rewards", "dones"):
             assert torch.equal(getattr(sa, name), getattr(sb, name)), (rollout, name, (getattr(sa, name).float() - getattr(sb, name).float()).abs().max())
         assert torch.equal(oa, o) and torch.equal(ea.rew_buf, eb.rew_buf) and torch.equal(ea.reset_buf, eb.reset_buf)
+        # the value of the last observation (PPO.compute_returns' last_values), evaluated at the end of the launch: the wave policy's value
+        # of that observation bit for bit, the torch critic's to rounding
+        tmp = _storage(N, 1)
+        eb.policy_act(fu.flat, o, 99, it, 0, tmp)
+        assert torch.equal(lv, tmp.values[0].view(-1))
+        with torch.no_grad():
+            torch.testing.assert_close(lv, ac.evaluate(o).view(-1), atol=3e-5, rtol=1e-5)
         assert torch.equal(ea.episode_length_buf, eb.episode_length_buf) and torch.equal(ea.time_out_buf, eb.time_out_buf)
         for x, y in zip(ea.get_state(), eb.get_state()):
             np.testing.assert_array_equal(x, y)
