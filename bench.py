@@ -315,6 +315,25 @@ def main():
                 roll = E * T * 5 / (time.perf_counter() - t1)
         except Exception as exc:       # a secondary figure: never fails the headline
             roll = f"failed: {type(exc).__name__}: {exc}"
+        # BASELINE config 5 on this one GPU: the reference's full PPO loop (train.py:54 -> OnPolicyRunner.learn: 80 steps per env, 5 epochs x 4
+        # mini-batches, the 54/42/30 networks) on the hand-written kernels, env-steps/s end to end, mean of iterations 6..15 of 16
+        ppo_e2e = None
+        if world == 1:
+            try:
+                from nightmare_rl_amd.envs.helpers import class_to_dict
+                from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3ConfigPPO
+                from nightmare_rl_amd.rl import OnPolicyRunner
+                torch.manual_seed(0)
+                cfgp = NightmareV3Config()
+                cfgp.env.num_envs = E
+                envp = NightmareV3Env(cfgp, device=dev, seed=0)
+                runner = OnPolicyRunner(envp, class_to_dict(NightmareV3ConfigPPO()), log_dir=None, device=str(dev))
+                runner.learn(16, init_at_random_ep_len=True)
+                h = runner.history[6:]
+                ppo_e2e = sum(r["fps"] for r in h) / len(h)
+                envp.close()
+            except Exception as exc:   # a secondary figure: never fails the headline
+                ppo_e2e = f"failed: {type(exc).__name__}: {exc}"
         # the fp64 verification build of the same kernel (what the exact-parity tests run)
         cfg64 = NightmareV3Config()
         cfg64.env.num_envs = E
@@ -349,7 +368,7 @@ def main():
                          "note": "latency/VALU-issue bound, not HBM bound: see DESIGN.md"},
             "physics_only_env_steps_per_s": phys,
             "closed_loop_mlp_2x256_env_steps_per_s": closed,
-            "policy_rollout_one_launch_env_steps_per_s": roll,
+            "policy_rollout_one_launch_env_steps_per_s": roll, "ppo_end_to_end_env_steps_per_s": ppo_e2e,
             "fp64_verification_kernel_env_steps_per_s": f64,
             "counters": env.counters(),
         }
