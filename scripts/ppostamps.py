@@ -6,7 +6,7 @@ from nightmare_rl_amd import _lib
 from nightmare_rl_amd.rl import ActorCritic
 from nightmare_rl_amd.rl.fused import FusedUpdate
 torch.manual_seed(0)
-B = 81920
+B = int(os.environ.get("PPO_B", "81920"))
 ac = ActorCritic(66, 66, 18, actor_hidden_dims=[54, 42, 30], critic_hidden_dims=[54, 42, 30], activation="elu", init_noise_std=1.0).cuda()
 opt = torch.optim.Adam(ac.parameters(), lr=1e-3)
 fu = FusedUpdate(ac, opt, "cuda:0", lr=1e-3)
