@@ -53,6 +53,8 @@ struct PpoNet {
   const f32x4* pb[kL];         // backward packing  [K tile][o group][lane]
   int slot[kWaves][kSlots];    // dW tiles of wave w: layer | o tile << 4 | k tile << 8, -1 = none (tile g of the network goes to wave g % 8)
   int slot4[4][16];                    // split kernel (k_ppo_fwdbwd_split): dW tiles of row-group wave g of either net, layer by layer: o tile | k tile << 4, -1 = none
+  int woff[2][kL], boff[2][kL];        // split kernel: flat-parameter index of W[0][0] / b[0] of net (actor, critic), layer l; nparam_flat: all of them
+  int nparam_flat;
   const f32x4* sf[2];                  // split kernel: per net (actor, critic), forward fragments in consumption order
   const f32x4* sb[2];                  // ... and the dX fragments
 };
@@ -772,26 +774,27 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
     });
   }
   PPO_STAMP(13);
-  // ---- this workgroup's partial gradient, at the positions of the merged layout (what k_ppo_step / k_ppo_reduce and the map expect):
-  // element (o, k) of net's layer-l matrix -> row o0 + o, column k0 + k of the merged [Op x Kp] block, its bias column -> column Kr
+  // ---- this workgroup's partial gradient, in FLAT parameter order (actor W0 b0 ..., critic ..., std): row v of `partial` is then read by
+  // k_ppo_step / k_ppo_reduce as it stands - 256 contiguous bytes per wave and row, no map indirection, no gaps (in the merged layout
+  // the 15 k parameters lie spread over 28 k positions: half again as many cache lines per row). The scalars keep their place behind gtotal.
   float* P = partial + (size_t)vb * (net.gtotal + kNS);
   sfor<NL>([&](auto L) {
-    constexpr int l = L;
-    const int no = critic ? S::cout(l) : S::aout(l), o0 = critic ? S::aout(l) : 0, k0 = (critic && l > 0) ? S::ain(l) : 0;
+    constexpr int l = L, in = X::in(l);
+    const int no = critic ? S::cout(l) : S::aout(l), wo = net.woff[nt][l], bo = net.boff[nt][l];
     sfor<X::slots(l)>([&](auto SI) {
       constexpr int slot = X::slotbase(l) + SI;
       const int code = net.slot4[g][slot];
       if (code >= 0) {
         const int kk = 16 * (code >> 4) + r;
-        const int km = kk < X::in(l) ? k0 + kk : net.Kr[l];
 #pragma unroll
         for (int reg = 0; reg < 4; reg++) {
           const int o = 16 * (code & 15) + 4 * q + reg;
-          if (o < no && kk <= X::in(l)) P[net.goff[l] + (o0 + o) * net.Kp[l] + km] = gw[slot][reg];
+          if (o < no && kk <= in) P[kk < in ? wo + o * in + kk : bo + o] = gw[slot][reg];
         }
       }
     });
   });
+  PPO_STAMP(13);
   for (int o = 1; o < 64; o <<= 1) { a_kl += __shfl_xor(a_kl, o); a_surr += __shfl_xor(a_surr, o); a_vl += __shfl_xor(a_vl, o); }
   __syncthreads();                       // every wave has left its last dW: the exchange buffer is free for the closing sums
   sfor<PO>([&](auto T) {
@@ -806,11 +809,13 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
   });
   if (lane == 0) { hsum[w][32] = a_kl; hsum[w][33] = a_surr; hsum[w][34] = a_vl; }
   __syncthreads();
-  // the actor block owns scalars 0..33 (d loss / d sigma, KL, surrogate) of the partial row, the critic block scalar 34 (value loss)
+  // the actor block owns d loss / d sigma (flat parameters nparam - A ..), KL and surrogate (scalars 32, 33 behind gtotal), the critic block
+  // the value loss (scalar 34)
   if (critic ? tid == 34 : tid < 34) {
     float v = 0.0f;
     for (int gg = 0; gg < kSplitWaves; gg++) v += hsum[gg][tid];
-    P[net.gtotal + tid] = v;
+    if (tid >= 32) P[net.gtotal + tid] = v;
+    else if (tid < AO) P[net.nparam_flat - AO + tid] = v;
   }
   PPO_STAMP(14);
 }
@@ -1006,7 +1011,7 @@ __global__ void k_ppo_scatter(const float* __restrict__ flat, const int* __restr
 // plus the entropy bonus -c_e * d(sum_j log std_j)/d(std_j))
 constexpr int kRedParams = 64, kRedWaves = 8;    // (16 waves per block measured no faster: 31.0 vs 29.8 us for k_ppo_step)
 __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const float* __restrict__ partial, int nwg, int stride, const int* __restrict__ map, int n, int gtotal,
-                             const float* __restrict__ flat, float ent_coef, float inv_B, float* __restrict__ grad) {
+                             const float* __restrict__ flat, float ent_coef, float inv_B, float* __restrict__ grad, int compact) {
   // entry n (one past the parameters) = this mini-batch's mean KL to the behaviour policy: it travels with the gradient through a
   // multi-GPU all-reduce. A block sums 64 consecutive parameters: wave w takes workgroups w, w + 8, ... (independent loads, 256 B runs), LDS joins the waves
   // in a fixed order - the result does not depend on scheduling
@@ -1017,7 +1022,8 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_reduce(const flo
   int m = 0;
   if (i <= n) {
     m = i < n ? map[i] : -33;
-    const float* P = partial + (m >= 0 ? m : gtotal + (-m - 1));
+    // compact: the rows are in flat parameter order (k_ppo_fwdbwd_split), else in the merged layout (map)
+    const float* P = partial + (compact ? (i < n ? i : gtotal + 32) : (m >= 0 ? m : gtotal + (-m - 1)));
     float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
     int w = w0;
     for (; w + 3 * kRedWaves < nwg; w += 4 * kRedWaves) {
@@ -1104,6 +1110,7 @@ struct StepArgs {
   unsigned* bar;                                // [0] arrivals, [1] generation
   float ent_coef, inv_B, desired_kl, max_norm, kl_override, b1, b2, eps;
   int adaptive, kl_from_grad, do_reduce;
+  int compact;                                  // the partial rows are in flat parameter order (k_ppo_fwdbwd_split)
 };
 __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a) {
   __shared__ float part[kRedWaves][kRedParams];
@@ -1116,7 +1123,7 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a)
   if (i <= n) mp = i < n ? a.map[i] : -33;
   if (a.do_reduce) {       // k_ppo_reduce's arithmetic and summation order
     if (i <= n) {
-      const float* P = a.partial + (mp >= 0 ? mp : a.gtotal + (-mp - 1));
+      const float* P = a.partial + (a.compact ? (i < n ? i : a.gtotal + 32) : (mp >= 0 ? mp : a.gtotal + (-mp - 1)));
       float g0 = 0.0f, g1 = 0.0f, g2 = 0.0f, g3 = 0.0f;
       int w = w0;
       for (; w + 3 * kRedWaves < a.nwg; w += 4 * kRedWaves) {
@@ -1329,6 +1336,14 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
   }
   for (int j = 0; j < h->A; j++) map.push_back(-(j + 1));
   h->nparam = (int)map.size();
+  {   // where each net's layers start in the flat vector (the order of the loop above)
+    int at = 0;
+    for (int net_i = 0; net_i < 2; net_i++) {
+      const int32_t* d = net_i ? critic_dims : actor_dims;
+      for (int l = 0; l < n_layers; l++) { n.woff[net_i][l] = at; at += d[l + 1] * d[l]; n.boff[net_i][l] = at; at += d[l + 1]; }
+    }
+    n.nparam_flat = h->nparam;
+  }
   // from here on a failure must release the handle (and what it already owns)
 #define PPO_CHK_H(x) do { if ((x) != hipSuccess) { nm_ppo_destroy(h); return nm_policy_set_error("nm_ppo_create: " #x " failed"); } } while (0)
   hipDeviceProp_t prop;
@@ -1459,7 +1474,7 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_split<RefShape>, dim3(2 * grid), dim3(64 * kSplitWaves), 0, s, h->net, bt, h->partial);      // two blocks (actor, critic) per partial row
     else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
     if (phase == 1 || !h->fused_step)
-      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nrows, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad);
+      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nrows, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad, h->fast ? 1 : 0);
   }
   if ((phase == 0 || phase == 2) && h->fused_step) {     // reduce (phase 0) + scalars + Adam + both packings: one launch
     StepArgs a;
@@ -1467,6 +1482,7 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     a.flat = flat_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev; a.grad = h->grad; a.state = h->state; a.Wm = h->Wm; a.n2part = h->n2part;
     a.pf = reinterpret_cast<float*>(h->pf); a.pb = reinterpret_cast<float*>(h->pb); a.pfi = h->pfi; a.pbi = h->pbi; a.bar = h->bar;
     a.sf = h->sf; a.sb = h->sb; a.sfi = h->sfi; a.sbi = h->sbi;
+    a.compact = h->fast ? 1 : 0;
     a.ent_coef = entropy_coef; a.inv_B = 1.0f / (float)B; a.desired_kl = desired_kl; a.max_norm = max_grad_norm; a.kl_override = kl_override;
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adaptive = adaptive; a.kl_from_grad = phase == 2 ? 1 : 0; a.do_reduce = phase == 0 ? 1 : 0;
     hipLaunchKernelGGL(k_ppo_step, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, a);
