@@ -513,8 +513,12 @@ __global__ void __launch_bounds__(64 * kSplitWaves, 2) k_ppo_fwdbwd_split(PpoNet
                         // output tiles of a pair are the same chain and the compiler drops one of them (260 MFMAs instead of 432)
     return f32x4{__int_as_float(wlane + 64 * i), 1.0f + i, 0.5f + i, 0.25f + i};
 #else
-    // (a wave-uniform fragment base + a 32-bit byte offset per lane: global_load with an SGPR base, no 64-bit address arithmetic per load)
-    return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>((fwd ? WF : WB) + i * 64) + wlane);
+    // A wave-uniform base + a 32-bit byte offset per lane: global_load with an SGPR base, no 64-bit address arithmetic per load. One base
+    // per FOUR fragments (4 KB) and the instruction's immediate offset inside it: a base per fragment is 64 SGPR pairs that the compiler
+    // hoists out of the pass loop, spills into VGPR lanes and fetches back with two v_readlane + s_nop in front of every load.
+    constexpr int grp = i >> 2, sub = i & 3;
+    const char* base = reinterpret_cast<const char*>((fwd ? WF : WB) + grp * 256);
+    return *reinterpret_cast<const f32x4*>((base + wlane) + sub * 1024);
 #endif
   };
   if (vb < npass) load_rows(vb, nx);
