@@ -77,12 +77,14 @@ def cpu_baseline(envs=4096):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks, one per GPU (default: WORLD_SIZE under a launcher, else 1)")
     ap.add_argument("--steps", type=int, default=1000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    if args.gpus is None:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -150,8 +152,8 @@ def main():
             returns.zero_()
             ncoll += 1
 
-    def sync():
-        if world > 1:
+    def sync(collective=True):
+        if world > 1 and collective:
             dist.barrier()
         # spin on an event first: the blocking wait behind torch.cuda.synchronize() wakes up tens of microseconds after the last
         # kernel has ended, which a 20-step timed region (1.2 ms) would carry as 3 us per step
@@ -164,15 +166,11 @@ def main():
     # Steady state first ("steady state, after >= 100 warm-up steps"): a timed region of a millisecond at the start of a process
     # runs at the clocks of an idle GPU (scripts/warmclock.py: 57.8 us/step cold, 53.4 after 0.2 s of sustained load - round 3 reported the
     # difference as `same_region_at_sustained_clock`). So before the W warm-up steps the caller asks for, the same step() runs untimed until
-    # 0.25 s of load have passed (and at least 100 warm-up steps in total); the count is in the line as `settle_steps`. No collective in here.
-    settle, t_settle = 0, time.perf_counter()
-    while settle < max(0, 100 - args.warmup) or time.perf_counter() - t_settle < 0.25:
-        for i in range(128):
-            env.step(acts[(settle + i) % pool])
-        settle += 128
-        torch.cuda.synchronize(dev)
-        if settle >= 20000:
-            break
+    # about 0.25 s of load have passed (and at least 100 warm-up steps in total); the count is in the line as `settle_steps`. No collective in here.
+    settle = max(0, 100 - args.warmup) + 4608          # a FIXED count: 4608 steps = 0.25 s at 54 us; the state entering the timed region is reproducible
+    for i in range(settle):
+        env.step(acts[i % pool])
+    torch.cuda.synchronize(dev)
     returns.zero_()
     for i in range(args.warmup):
         one_step(i, last=i == args.warmup - 1)
@@ -215,6 +213,52 @@ def main():
         k_ms, k_n = env.profile(False)
         k_avg_pairs = k_ms / max(k_n, 1) * 1e-3
         achieved = B_FULL * E / k_avg / 1e9
+        # The regime training runs in: random U(-1,1) actions keep the robots flailing (about 1.4 floor contacts per
+        # env), a policy that has learnt to stand keeps 4..6 feet down (5.3 on average after 150 PPO iterations, profiles/r04_trained_policy_regime.txt)
+        # and the constraint stage then solves 16..24 rows per env. The standing regime is reproduced without a checkpoint by SMALL actions
+        # around the servo's rest pose: 0.12 x the same U(-1,1) stream (zero actions = all six feet down). Same kernel, same launch count,
+        # its own event pair; the contact histogram of both regimes is read from the kernel's debug buffer in untimed steps.
+        def contact_hist(action_scale, nsteps=40):
+            dbg = torch.zeros(E, 256, device=dev)
+            env.set_debug_buffer(dbg)
+            h = np.zeros(48, dtype=np.int64)
+            for i in range(nsteps):
+                env.step(acts[i % pool] * action_scale)
+                h += np.bincount(dbg[:, 160].cpu().numpy().astype(np.int64), minlength=48)[:48]
+            env.set_debug_buffer(None)
+            return {"mean_contacts_per_env": float((h * np.arange(48)).sum() / h.sum()), "histogram": {int(k): int(v) for k, v in enumerate(h) if v}}
+        regime = None
+        try:
+            hist_random = contact_hist(1.0)
+            kScale = 0.12
+            acts_stand = (acts * kScale).contiguous()
+            env.reset()
+            for i in range(300):                                  # settle into the stance
+                env.step(acts_stand[i % pool])
+            hist_stand = contact_hist(kScale)
+            for i in range(20):
+                env.step(acts_stand[i % pool])
+            e0.record(stream)
+            for i in range(n_leg):
+                env.step(acts_stand[i % pool])
+            e1.record(stream)
+            e1.synchronize()
+            ks = e0.elapsed_time(e1) / n_leg * 1e-3
+            sync(collective=False)                               # rank 0 only in here: no barrier
+            t1 = time.perf_counter()
+            for i in range(args.steps):
+                env.step(acts_stand[i % pool])
+            sync(collective=False)
+            dts = time.perf_counter() - t1
+            regime = {"actions": f"{kScale} x U(-1,1)^18 around the servo rest pose: the robots stand (the regime of a trained policy: 5.3 contacts per env)",
+                      "value": E * args.steps / dts, "ms_per_step": dts / args.steps * 1e3, "kernel_avg_us": ks * 1e6, "kernel_launches_timed": n_leg,
+                      "roofline_frac_hbm": B_FULL * E / ks / 1e9 / HBM_PEAK_GBS, **hist_stand,
+                      "headline_regime": {"actions": "U(-1,1)^18", "kernel_avg_us": k_avg * 1e6, **hist_random}}
+            env.reset()
+            for i in range(100):
+                env.step(acts[i % pool])
+        except Exception as exc:       # a secondary figure: never fails the headline
+            regime = f"failed: {type(exc).__name__}: {exc}"
         # The same region once more (reset, W warm-up steps, K timed steps) right after the >= 600 back-to-back launches above: a short
         # timed region at the start of a process runs at the clocks of an idle GPU (scripts/warmclock.py: 57.8 us/step cold, 53.4 us/step
         # after 0.2 s of sustained load); `value` above is the cold one when --steps is small. Reported, not used for `value`.
@@ -366,6 +410,7 @@ def main():
                          "algorithmic_bytes_per_env_step": B_FULL,
                          "valu": valu, "valu_fp32": valu_fp32,
                          "note": "latency/VALU-issue bound, not HBM bound: see DESIGN.md"},
+            "contact_regime": regime,
             "physics_only_env_steps_per_s": phys,
             "closed_loop_mlp_2x256_env_steps_per_s": closed,
             "policy_rollout_one_launch_env_steps_per_s": roll, "ppo_end_to_end_env_steps_per_s": ppo_e2e,

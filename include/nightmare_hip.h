@@ -204,6 +204,17 @@ int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float*
                           const float* old_mu, const float* old_sigma, const float* old_logp, const float* adv, const float* ret, const float* target_values,
                           const int32_t* rows_dev, int32_t B, int32_t n_obs, float clip, float value_coef, float entropy_coef, int32_t clip_value, float desired_kl,
                           int32_t adaptive, float max_grad_norm, float beta1, float beta2, float eps, int32_t phase, float kl_override, void* stream);
+/* Declares how many rows the [T*N, .] arrays behind a row list hold (row numbers are in [0, n_rows)); must precede nm_ppo_minibatch_rows with
+ * rows_dev != NULL. LIMIT: the kernels address a row as base + a 32-bit byte offset, so n_rows * max(n_obs, n_actions) * 4 must stay below
+ * 2^32 (16.2 M rows of 66 floats; BASELINE config 5 has 32768 x 80 = 2.6 M); beyond it this call - and nm_ppo_minibatch for B - fails. */
+int nm_ppo_set_storage_rows(nm_ppo* h, int64_t n_rows);
+/* 1 if the mini-batch step of this handle is the one-launch k_ppo_step (one grid barrier), 0 if it is the four-launch chain: asked for with
+ * NM_PPO_UNFUSED_STEP=1, chosen at creation because the device cannot hold the step's grid at once (occupancy query), or after a barrier
+ * time-out. A barrier that times out makes that step and every later fused step a NO-OP (no parameter, moment or packed weight is written)
+ * until nm_ppo_get_state has reported it. */
+int32_t nm_ppo_step_is_fused(const nm_ppo* h);
+/* TEST HOOK: the next fused step's grid barrier will time out (about one second of spinning), to exercise the no-op path. */
+int nm_ppo_debug_break_barrier(nm_ppo* h, void* stream);
 /* The mini-batch order of one PPO.update (rsl_rl v1.0.2 mini_batch_generator: indices = torch.randperm(num_mini_batches * mini_batch_size)):
  * out_dev[i] (int32) = image of i under a pseudo-random permutation of 0..n-1 keyed by (seed, counter) - a cycle-walked Feistel network,
  * one launch, no sort. */

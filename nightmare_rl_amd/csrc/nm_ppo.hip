@@ -1103,8 +1103,9 @@ __global__ void k_ppo_adam(float* __restrict__ flat, float* __restrict__ m, floa
 // gradient norm: every block publishes the sum of squares of its 64 gradients (device-scope atomic), one grid barrier, then every block
 // adds the nblk partial sums in the same fixed order - so all blocks (and, after an all-reduce, all ranks) get the same clip coefficient
 // bit for bit - and evaluates the KL-adaptive learning rate itself from the workgroups' scalar tails; block 0 files the state.
-// nblk (~236) blocks of 512 threads are co-resident on the 256 CUs, which the spinning barrier needs; the spin is bounded (state[8] = 1
-// on a time-out: nm_ppo_get_state reports it).
+// nblk (~236) blocks of 512 threads are co-resident on the 256 CUs, which the spinning barrier needs: nm_ppo_create asks the runtime
+// (hipOccupancyMaxActiveBlocksPerMultiprocessor x the CU count) and keeps the four-launch step when the grid does not fit. The spin is
+// bounded; a time-out turns the step into a no-op for EVERY block (state[8] = 1, nm_ppo_get_state / nm_ppo_snapshot_state report it).
 struct StepArgs {
   const float* partial; int nwg, stride, gtotal;
   const int* map; int n;
@@ -1158,22 +1159,41 @@ __global__ void __launch_bounds__(kRedParams * kRedWaves) k_ppo_step(StepArgs a)
     // release / acquire on the barrier flag, took 110 us instead of 20)
     if (lane == 0) { const float was = atomicExch(a.n2part + b, s); asm volatile("" ::"v"(was) : "memory"); }
   }
-  // ---- grid barrier (one per launch): the last block to arrive re-arms the counter and opens the next generation
+  // ---- grid barrier (one per launch): the last block to arrive re-arms the counter and opens the next generation.
+  // bar[1] is the generation AND the verdict: a launch that starts at the even value `gen` ends at gen + 2 (every block arrived) or at
+  // gen + 1 (a block gave up waiting: the workgroups were not co-resident). Both transitions are a compare-and-swap from `gen`, so exactly
+  // one of them happens and every block reads the same verdict. A FAILED barrier makes the whole step a no-op - no block writes flat, m, v,
+  // the packings or the state (a step taken on an incomplete norm must not reach the parameters, let alone a checkpoint) - and
+  // the odd generation is sticky: every later launch returns here without arriving, until nm_ppo_get_state has reported the failure and
+  // reset the barrier (it then switches the handle to the four-launch step).
+  __shared__ unsigned s_fail;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const unsigned old = atomicAdd(a.bar, 1u);
-    if (old == gridDim.x - 1) {
-      __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(a.bar + 1, gen + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-      int spins = 0;
-      while (__hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-        __builtin_amdgcn_s_sleep(4);
-        if (++spins > (1 << 22)) { a.state[8] = 1.0f; break; }     // never on an idle GPU; a hung barrier must not hang the device
+    unsigned fail = gen & 1u;
+    if (!fail) {
+      const unsigned old = atomicAdd(a.bar, 1u);
+      if (old == gridDim.x - 1) {
+        __hip_atomic_store(a.bar, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fail = atomicCAS(a.bar + 1, gen, gen + 2u) != gen;       // a block that timed out has decided first
+      } else {
+        int spins = 0;
+        unsigned v;
+        while ((v = __hip_atomic_load(a.bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == gen) {
+          __builtin_amdgcn_s_sleep(4);
+          if (++spins > (1 << 22)) {      // never on an idle GPU; a hung barrier must not hang the device
+            v = atomicCAS(a.bar + 1, gen, gen + 1u);
+            if (v == gen) v = gen + 1u;   // this block's verdict stands; otherwise the last block arrived (or another one gave up) just before
+            break;
+          }
+        }
+        fail = v & 1u;
       }
     }
+    if (fail) __hip_atomic_store(a.state + 8, 1.0f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_fail = fail;
   }
   __syncthreads();
+  if (s_fail) return;
   if (w0 != 0) return;
   // ---- the scalars of k_ppo_scalars, by every block in the same order
   float n2 = 0.0f, kl = 0.0f, su = 0.0f, vl = 0.0f;
@@ -1245,6 +1265,8 @@ struct nm_ppo {
   float* n2part = nullptr;
   unsigned* bar = nullptr;
   bool fused_step = true;                   // NM_PPO_UNFUSED_STEP=1: the four launches (reduce, scalars, adam, pack) - A/B timing and tests
+  int64_t storage_rows = 0;                 // rows of the [T*N, .] arrays nm_ppo_minibatch_rows gathers from (nm_ppo_set_storage_rows)
+  int step_grid_capacity = 0;               // workgroups of k_ppo_step the device holds at once (occupancy query at creation)
   std::vector<size_t> pf_off, pb_off;
 };
 
@@ -1418,6 +1440,14 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
     for (int net_i = 0; net_i < 2; net_i++) { n.sf[net_i] = reinterpret_cast<const f32x4*>(h->sf + net_i * nfw); n.sb[net_i] = reinterpret_cast<const f32x4*>(h->sb + net_i * nbw); }
   }
   h->fused_step = !(std::getenv("NM_PPO_UNFUSED_STEP") && std::atoi(std::getenv("NM_PPO_UNFUSED_STEP")) != 0);
+  if (h->fused_step) {      // the grid barrier of k_ppo_step needs every workgroup of its grid resident at once: ask, do not assume
+    int per_cu = 0, cus = 0;
+    const int nbr = (h->nparam + 1 + kRedParams - 1) / kRedParams;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_ppo_step, kRedParams * kRedWaves, 0) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess || (long)per_cu * cus < nbr)
+      h->fused_step = false;
+    h->step_grid_capacity = per_cu * cus;
+  }
   PPO_CHK_H(hipMemset(h->partial, 0, (size_t)h->nwg * (n.gtotal + kNS) * sizeof(float)));
 #undef PPO_CHK_H
   for (int l = 0; l < n_layers; l++) { n.pf[l] = h->pf + h->pf_off[l]; n.pb[l] = h->pb + h->pb_off[l]; }
@@ -1456,6 +1486,14 @@ extern "C" int nm_ppo_minibatch(nm_ppo* h, float* flat_dev, float* exp_avg_dev, 
   return nm_ppo_minibatch_rows(h, flat_dev, exp_avg_dev, exp_avg_sq_dev, obs, actions, old_mu, old_sigma, old_logp, adv, ret, tval, nullptr, B, n_obs, clip, value_coef,
                                entropy_coef, clip_value, desired_kl, adaptive, max_grad_norm, beta1, beta2, eps, phase, kl_override, stream);
 }
+// rows of the arrays a row list indexes: row numbers are in [0, n_rows); n_rows * max(n_obs, n_actions) * 4 must stay below 2^32
+extern "C" int nm_ppo_set_storage_rows(nm_ppo* h, int64_t n_rows) {
+  if (!h || n_rows <= 0) return nm_policy_set_error("nm_ppo_set_storage_rows: bad argument");
+  if (n_rows * std::max(h->net.Kr[0], h->A) * 4 >= ((int64_t)1 << 32))
+    return nm_policy_set_error("nm_ppo_set_storage_rows: the in-kernel row gather uses 32-bit byte offsets: n_rows * max(n_obs, n_actions) * 4 must stay below 2^32");
+  h->storage_rows = n_rows;
+  return 0;
+}
 // the same with the mini-batch given as row numbers into the (unpermuted) arrays: row i of the mini-batch is row rows_dev[i] - the gather
 // of rsl_rl's mini_batch_generator (obs[batch_idx], ...) happens inside the forward / backward kernel. rows_dev == NULL: rows 0..B-1.
 extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_dev, float* exp_avg_sq_dev, const float* obs, const float* actions,
@@ -1465,6 +1503,12 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
   if (!h || !flat_dev || !exp_avg_dev || !exp_avg_sq_dev || !obs || !actions || !old_mu || !old_sigma || !old_logp || !adv || !ret || !tval || B <= 0)
     return nm_policy_set_error("nm_ppo_minibatch: bad argument");
   if (n_obs != h->net.Kr[0]) return nm_policy_set_error("nm_ppo_minibatch: observation width does not match the network");
+  {  // the kernels address a row as a uniform base + a 32-bit BYTE offset per lane (row * width * 4): the arrays a row number can reach
+     // must stay under 4 GiB - B rows without a row list, the declared storage (nm_ppo_set_storage_rows) with one
+    const int64_t reach = rows_dev ? h->storage_rows : (int64_t)B, widest = std::max(n_obs, h->A);
+    if (rows_dev && h->storage_rows <= 0) return nm_policy_set_error("nm_ppo_minibatch_rows: declare the row count of the arrays with nm_ppo_set_storage_rows first");
+    if (reach * widest * 4 >= ((int64_t)1 << 32)) return nm_policy_set_error("nm_ppo_minibatch: more than 2^32 bytes per array (32-bit row offsets): split the storage");
+  }
   PPO_CHK(hipSetDevice(h->device));
   hipStream_t s = (hipStream_t)stream;
   const int stride = h->net.gtotal + kNS, nb = (h->nparam + 255) / 256, nbr = (h->nparam + 1 + kRedParams - 1) / kRedParams;
@@ -1557,6 +1601,26 @@ extern "C" int nm_ppo_permutation(int32_t* out_dev, int32_t n, uint64_t seed, ui
 // the same nine values (out[8] != 0: k_ppo_step's grid barrier timed out) copied to DEVICE memory, stream-ordered and without a host
 // synchronisation: the caller reads them (e.g. through a pinned host copy) whenever it likes - the runner does so one iteration later, while
 // the next rollout is already running
+// after a failed grid barrier: re-arm it (arrivals 0, even generation), clear the flag, and keep away from the fused step for good
+static int ppo_reset_barrier(nm_ppo* h, hipStream_t s) {
+  PPO_CHK(hipMemsetAsync(h->bar, 0, 2 * sizeof(unsigned), s));
+  PPO_CHK(hipMemsetAsync(h->state + 8, 0, sizeof(float), s));
+  h->fused_step = false;
+  return 0;
+}
+// 1 if this handle's mini-batch step is the one-launch k_ppo_step, 0 if it is the four-launch chain (asked for, the grid would not be
+// co-resident, or a barrier has failed)
+extern "C" int32_t nm_ppo_step_is_fused(const nm_ppo* h) { return h && h->fused_step ? 1 : 0; }
+// TEST HOOK: make the NEXT fused step's barrier time out (the arrival count is moved out of reach), to prove the no-op behaviour on a GPU
+// that would otherwise never show it. Costs that launch ~1 s of spinning.
+extern "C" int nm_ppo_debug_break_barrier(nm_ppo* h, void* stream) {
+  if (!h) return nm_policy_set_error("nm_ppo_debug_break_barrier: bad argument");
+  PPO_CHK(hipSetDevice(h->device));
+  const unsigned far = 1u << 30;
+  PPO_CHK(hipMemcpyAsync(h->bar, &far, sizeof(unsigned), hipMemcpyHostToDevice, (hipStream_t)stream));
+  PPO_CHK(hipStreamSynchronize((hipStream_t)stream));
+  return 0;
+}
 extern "C" int nm_ppo_snapshot_state(nm_ppo* h, float* out9_dev, int32_t reset_sums, void* stream) {
   if (!h || !out9_dev) return nm_policy_set_error("nm_ppo_snapshot_state: bad argument");
   PPO_CHK(hipSetDevice(h->device));
@@ -1575,9 +1639,10 @@ extern "C" int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums,
   PPO_CHK(hipStreamSynchronize(s));
   for (int i = 0; i < 8; i++) out8_host[i] = st[i];
   if (reset_sums) PPO_CHK(hipMemsetAsync(h->state + 3, 0, 3 * sizeof(float), s));
-  if (st[8] != 0.0f) {      // k_ppo_step's grid barrier gave up waiting (its blocks were not co-resident): the step it took is not trustworthy
-    PPO_CHK(hipMemsetAsync(h->state + 8, 0, sizeof(float), s));
-    return nm_policy_set_error("nm_ppo: the grid barrier of the fused mini-batch step timed out (GPU shared with another job?); set NM_PPO_UNFUSED_STEP=1");
+  if (st[8] != 0.0f) {      // k_ppo_step's grid barrier gave up waiting (its blocks were not co-resident): that step and every one since was a no-op
+    if (ppo_reset_barrier(h, s)) return 1;
+    return nm_policy_set_error("nm_ppo: the grid barrier of the fused mini-batch step timed out (GPU shared with another job?); the mini-batch steps "
+                               "since then were skipped (no parameter written); this handle now takes the four-launch step (NM_PPO_UNFUSED_STEP=1)");
   }
   return 0;
 }

@@ -92,27 +92,40 @@ def axis_angle_quat(axis, angle):
 
 
 # ----------------------------------------------------------------------------- STL / mesh
-def load_stl(path, scale):
-    """Binary STL -> (verts float64 [n,3] deduplicated, faces int [m,3]).
+def load_stl_raw(path):
+    """Binary STL -> (verts float32 [n,3] de-duplicated in file order, faces int [m,3]); the RAW file floats, nothing scaled.
 
-    MuJoCo keeps mesh vertices in float32 and removes repeated vertices
-    (user_mesh.cc LoadSTL / RemoveRepeated); the scale multiply is done in float32 too.
+    MuJoCo reads the triangle list into a float32 vertex array and removes repeated vertices IN FILE ORDER (user_mesh.cc LoadSTL /
+    RemoveRepeated: the i-th distinct vertex is the i-th one to appear in the triangle list; the array is compressed in place, not
+    sorted). The order matters downstream: qhull's facet list - and with it the neighbour order of the hull graph, which decides WHICH
+    <= 3 extra plane-mesh contacts are kept - depends on the order of its input points. (np.unique alone would hand back the vertices
+    sorted by coordinate.) The de-duplication runs on the raw floats, BEFORE any scaling, as upstream's does.
     """
     raw = open(path, "rb").read()
     n = struct.unpack("<I", raw[80:84])[0]
     assert len(raw) == 84 + 50 * n, f"{path}: not a binary STL"
     rec = np.frombuffer(raw, dtype=np.dtype([("n", "<f4", 3), ("v", "<f4", (3, 3)), ("a", "<u2")]), offset=84, count=n)
-    tri = (rec["v"].astype(np.float32) * np.asarray(scale, dtype=np.float32)).reshape(-1, 3)
-    # Repeated vertices are removed IN FILE ORDER: the i-th distinct vertex is the i-th one to appear in the triangle list (MuJoCo's
-    # RemoveRepeated compresses the vertex array in place, it does not sort it). The order matters downstream: qhull's facet list - and
-    # with it the neighbour order of the hull graph, which decides WHICH <= 3 extra plane-mesh contacts are kept - depends on the order
-    # of its input points. (np.unique alone would hand back the vertices sorted by coordinate.)
+    tri = rec["v"].astype(np.float32).reshape(-1, 3)
     uniq, first, inv = np.unique(tri, axis=0, return_index=True, return_inverse=True)
     order = np.argsort(first, kind="stable")         # distinct vertices by first occurrence
     rank = np.empty(len(order), dtype=np.int64)
     rank[order] = np.arange(len(order))
     faces = rank[np.asarray(inv).reshape(-1)].reshape(-1, 3)
-    return uniq[order].astype(np.float64), faces
+    return np.ascontiguousarray(uniq[order], dtype=np.float32), faces
+
+
+def scale_verts(raw32, scale):
+    """The mesh `scale` attribute as upstream applies it (user_mesh.cc `mjCMesh::Process`: `vert_[i] *= scale[j]` on a float array with a
+    double scale): the product is formed in double and rounded ONCE to float32 - not float32 x float32(scale)."""
+    s = np.asarray(scale, dtype=np.float64)
+    assert np.prod(s) > 0, "a negative scale flips the face winding (LoadSTL); not needed for this model"
+    return (raw32.astype(np.float64) * s).astype(np.float32)
+
+
+def load_stl(path, scale):
+    """(verts float64 [n,3] = the float32 vertices MuJoCo holds after scaling, faces): see load_stl_raw / scale_verts."""
+    raw32, faces = load_stl_raw(path)
+    return scale_verts(raw32, scale).astype(np.float64), faces
 
 
 def mesh_props(V, F, legacy=True):
@@ -374,7 +387,8 @@ def compile_model(xml_path):
     for b in range(1, nb):
         g = bodies[b]["geom"]
         fn, scale = mj["meshes"][g["mesh"]]
-        V, F = load_stl(os.path.join(mdir, fn), scale)
+        raw32, F = load_stl_raw(os.path.join(mdir, fn))
+        V = scale_verts(raw32, scale).astype(np.float64)       # what Process() computes mass / inertia on
         vol, com, I = mesh_props(V, F, legacy=True)
         vol_e, _, _ = mesh_props(V, F, legacy=False)
         Rg = quat_to_mat(g["quat"])
@@ -389,19 +403,32 @@ def compile_model(xml_path):
         iquat[b] = mat_to_quat(Rg @ U)
         inertia[b] = density * w
         if g["contype"] or g["conaffinity"]:
-            # centred principal frame (what MuJoCo stores in mesh_vert) -> rbound
-            Vp = (V - com) @ U
-            rb = np.linalg.norm(np.max(np.abs(Vp), axis=0))
-            vid, nbr = hull_with_graph(V)
-            Vb = g["pos"] + V[vid] @ Rg.T  # hull vertices in the BODY frame
+            # Upstream's order (user_mesh.cc mjCMesh::Compile, 3.1.2 [3P]): load + RemoveRepeated -> MakeGraph (qhull "Qt" on the vertex
+            # array AS LOADED: raw float32 file values cast to double, no scale, no centring) -> CopyGraph / MakeNormal -> Process()
+            # ("scale, center, orient, compute mass and inertia"). The graph holds point ids, so the later scaling does not touch it -
+            # but qhull's facet list, its Qt triangulation and even WHICH nearly coplanar points count as hull vertices depend on the
+            # last bits of its input, so the hull must be built from the unscaled values.
+            vid, nbr = hull_with_graph(raw32.astype(np.float64))
+            # mesh_vert as the model stores it: float32, re-centred at the COM and rotated into the principal frame, each step rounded to
+            # float32 (Process(): `vert -= CoM`, then `vert = eigvec' vert`); the geom frame absorbs COM and principal rotation
+            # (mjCGeom::Compile: geom pos/quat composed with the mesh's pos_volume / quat_volume), so at run time a hull vertex in the BODY
+            # frame is geom_pos + R(geom_quat) mesh_vert, evaluated in double.
+            Vc32 = (V - com).astype(np.float32)
+            Vp32 = (Vc32.astype(np.float64) @ U).astype(np.float32)
+            Vp = Vp32.astype(np.float64)
+            gpos = g["pos"] + Rg @ com
+            gmat = Rg @ U
+            rb = np.linalg.norm(np.max(np.abs(Vp), axis=0))     # geom_rbound: norm of the centred principal frame's half extents
+            Vb = gpos + Vp[vid] @ gmat.T                         # hull vertices in the BODY frame
             # oriented bounding box of the hull in the mesh's principal frame -> body frame (conservative pair cull on the GPU)
-            Hp = (V[vid] - com) @ U
+            Hp = Vp[vid]
             lo, hi = Hp.min(axis=0), Hp.max(axis=0)
-            obb_c = g["pos"] + Rg @ (com + U @ ((lo + hi) / 2))
-            obb_ax = (Rg @ U).T            # rows = box axes in the body frame
+            obb_c = gpos + gmat @ ((lo + hi) / 2)
+            obb_ax = gmat.T                # rows = box axes in the body frame
             obb_h = (hi - lo) / 2
             col.append(dict(body=b, name=g["name"], verts=Vb, nbr=nbr, rbound=rb, center=ipos[b].copy(), obb_c=obb_c, obb_ax=obb_ax, obb_h=obb_h,
-                            contype=g["contype"], conaffinity=g["conaffinity"]))
+                            contype=g["contype"], conaffinity=g["conaffinity"], mesh_vert=Vp32, vid=vid, gpos=gpos, gquat=mat_to_quat(gmat),
+                            nmeshvert=len(V)))
     scale = mj["settotalmass"] / mass.sum()
     mass *= scale
     inertia *= scale
@@ -431,6 +458,13 @@ def compile_model(xml_path):
             row += 1
     T["hull_nbr"] = nbr_tab
     T["hull_maxnbr"] = maxnbr
+    # what tests/test_mujoco_crosscheck.py compares with a real MjModel (npz only; the kernels use the body-frame tables above):
+    # the hull vertices as mesh_vert rows (float32, centred principal frame), their point ids in the de-duplicated mesh, the geom frame
+    T["col_mesh_nvert"] = np.array([c["nmeshvert"] for c in col], dtype=np.int32)
+    T["hull_mesh_vert"] = np.concatenate([c["mesh_vert"][c["vid"]] for c in col]).astype(np.float32)
+    T["hull_point_id"] = np.concatenate([c["vid"] for c in col]).astype(np.int32)
+    T["col_geom_pos"] = np.array([c["gpos"] for c in col])
+    T["col_geom_quat"] = np.array([c["gquat"] for c in col])
 
     # touch-sensor sites: 6 tibia (r=10), 6 foot (r=.007), base (r=10)  (mjmodel.xml:156-170)
     site = {s["name"]: (b, s) for b, bd in enumerate(bodies) for s in bd["sites"]}

@@ -251,6 +251,9 @@ class FusedUpdate:
         if rows is not None and (rows.dtype != torch.int32 or not rows.is_contiguous() or rows.device != self.flat.device):
             raise ValueError("minibatch: rows must be a contiguous int32 tensor on the update's device")
         B = obs.shape[0] if rows is None else int(rows.numel())
+        if rows is not None and getattr(self, "_storage_rows", None) != obs.shape[0]:
+            _lib.check(self._L.nm_ppo_set_storage_rows(self._h, int(obs.shape[0])))      # 32-bit row offsets in the kernel: refused beyond 4 GiB per array
+            self._storage_rows = obs.shape[0]
         _lib.check(self._L.nm_ppo_minibatch_rows(self._h, self.flat.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), obs.data_ptr(), actions.data_ptr(),
                                                  old_mu.data_ptr(), old_sigma.data_ptr(), old_logp.data_ptr(), advantages.data_ptr(), returns.data_ptr(),
                                                  target_values.data_ptr(), None if rows is None else rows.data_ptr(), B, obs.shape[1], hp["clip"], hp["value_coef"],
@@ -319,9 +322,11 @@ class FusedUpdate:
     def state_from(self, vals9):
         """dict like read_state() from the nine host floats of a snapshot."""
         if vals9[8] != 0.0:
-            raise _lib.NightmareHipError("nm_ppo: the grid barrier of the fused mini-batch step timed out (GPU shared with another job?); set NM_PPO_UNFUSED_STEP=1")
+            raise _lib.NightmareHipError("nm_ppo: the grid barrier of the fused mini-batch step timed out (GPU shared with another job?); the steps since "
+                                         "then were skipped (no parameter written); set NM_PPO_UNFUSED_STEP=1")
         st = dict(zip(self.STATE_KEYS, [float(x) for x in vals9[:8]]))
-        self.step_count = int(round(st["steps"]))
+        # a snapshot is one iteration old when it is read: the host's own count (advanced by every mini-batch enqueued since) is never moved back
+        self.step_count = max(self.step_count, int(round(st["steps"])))
         return st
 
     def publish_step(self):

@@ -196,91 +196,107 @@ class OnPolicyRunner:
                 collection = e0.elapsed_time(e1) * 1e-3
                 emit(it_, collection, max(total - collection, 0.0), vl, sl_, st["kl"], v[9:13], v[kSnap:kSnap + len(keys)] if keys else None, keys, ep_n, v[13], st["lr"])
 
-        for it in range(self.current_learning_iteration, tot_iter):
-            start = time.time()
-            if hasattr(alg, "begin_iteration"):
-                alg.begin_iteration(it)
-            if pipe:
-                if len(slots) < 2:
-                    slots.append((torch.zeros(64, dtype=torch.float32).pin_memory(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
-                                  torch.cuda.Event(enable_timing=True)))
-                sl = slots[(it - self.current_learning_iteration) % 2]
-                ev0, ev1 = sl[1], sl[2]
-                if pending:
-                    pending[-1][4] = sl            # the previous iteration ends where this one starts
-            if on_gpu:
-                ev0.record()
-            with torch.inference_mode():
-                if graph is not None:
-                    graph.replay()
-                    alg.storage.step = T         # what the captured add_transitions calls did on the host side
-                    env.common_step_counter += T
-                elif want_graph and it > self.current_learning_iteration and ep_acc is not None:
-                    # the first iteration ran eagerly (lazy initialisations done, buffers exist): capture the next one
-                    try:
-                        torch.cuda.synchronize()
-                        g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
-                            rollout()
-                        graph = g               # the capture did not execute anything: run this iteration from the graph
-                        alg.storage.clear()
-                        graph.replay()
-                        alg.storage.step = T
-                    except Exception as exc:     # keep training on the eager path
-                        want_graph = False
-                        alg.reset_collection() if hasattr(alg, "reset_collection") else alg.storage.clear()
-                        if log:
-                            print(f"rollout graph capture failed ({type(exc).__name__}: {exc}); staying on the eager path", flush=True)
-                        rollout()
-                else:
-                    rollout()
-                obs, critic_obs = state["obs"], state["critic_obs"]
-                ep_stats, ep_n = (ep_acc, T) if ep_acc is not None else (None, 0)
-                infos = env.extras
+        # with pipelined logging the host mirrors (Adam step count, learning rate) lag the device by one iteration until the
+        # queue is drained - so it IS drained on every way out of the loop (exception, KeyboardInterrupt), and save() drains first
+        self._drain_all = (lambda: drain(True)) if pipe else None
+        try:
+            for it in range(self.current_learning_iteration, tot_iter):
+                start = time.time()
+                if hasattr(alg, "begin_iteration"):
+                    alg.begin_iteration(it)
+                if pipe:
+                    if len(slots) < 2:
+                        slots.append((torch.zeros(64, dtype=torch.float32).pin_memory(), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True),
+                                      torch.cuda.Event(enable_timing=True)))
+                    sl = slots[(it - self.current_learning_iteration) % 2]
+                    ev0, ev1 = sl[1], sl[2]
+                    if pending:
+                        pending[-1][4] = sl            # the previous iteration ends where this one starts
                 if on_gpu:
-                    ev1.record()             # the rollout is asynchronous: its device time is read after the update has synchronised
-                collection_time = time.time() - start
-                step_rew = alg.storage.rewards.mean()
-                alg.compute_returns(critic_obs)
-            if pipe:
-                alg.update(defer=snap_dev[:9])
+                    ev0.record()
                 with torch.inference_mode():
-                    keys = list(state["ep_keys"]) if (ep_stats is not None and state["ep_keys"]) else []
-                    snap_dev[9:12].copy_(fin)
-                    snap_dev[12].copy_(step_rew)
-                    snap_dev[13].copy_(alg.actor_critic.std.detach().mean())
-                    if keys:
-                        snap_dev[kSnap:kSnap + len(keys)].copy_(ep_stats)
-                    sl[0].copy_(snap_dev, non_blocking=True)
-                sl[3].record()
-                pending.append([it, sl, keys, ep_n, None])
-                # a checkpoint must hold the state after ITS iteration: drain before the next one is enqueued; else lag by one iteration
-                drain(upto_all=(log and it % self.save_interval == 0) or it == tot_iter - 1)
-                continue
-            mean_value_loss, mean_surrogate_loss = alg.update()
-            kl = getattr(alg, "last_kl", float("nan"))
-            total_time = time.time() - start
-            if on_gpu:
-                torch.cuda.synchronize()
+                    if graph is not None:
+                        graph.replay()
+                        alg.storage.step = T         # what the captured add_transitions calls did on the host side
+                        env.common_step_counter += T
+                    elif want_graph and it > self.current_learning_iteration and ep_acc is not None:
+                        # the first iteration ran eagerly (lazy initialisations done, buffers exist): capture the next one
+                        try:
+                            torch.cuda.synchronize()
+                            g = torch.cuda.CUDAGraph()
+                            with torch.cuda.graph(g):
+                                rollout()
+                            graph = g               # the capture did not execute anything: run this iteration from the graph
+                            alg.storage.clear()
+                            graph.replay()
+                            alg.storage.step = T
+                        except Exception as exc:     # keep training on the eager path
+                            want_graph = False
+                            alg.reset_collection() if hasattr(alg, "reset_collection") else alg.storage.clear()
+                            if log:
+                                print(f"rollout graph capture failed ({type(exc).__name__}: {exc}); staying on the eager path", flush=True)
+                            rollout()
+                    else:
+                        rollout()
+                    obs, critic_obs = state["obs"], state["critic_obs"]
+                    ep_stats, ep_n = (ep_acc, T) if ep_acc is not None else (None, 0)
+                    infos = env.extras
+                    if on_gpu:
+                        ev1.record()             # the rollout is asynchronous: its device time is read after the update has synchronised
+                    collection_time = time.time() - start
+                    step_rew = alg.storage.rewards.mean()
+                    alg.compute_returns(critic_obs)
+                if pipe:
+                    alg.update(defer=snap_dev[:9])
+                    with torch.inference_mode():
+                        keys = list(state["ep_keys"]) if (ep_stats is not None and state["ep_keys"]) else []
+                        snap_dev[9:12].copy_(fin)
+                        snap_dev[12].copy_(step_rew)
+                        snap_dev[13].copy_(alg.actor_critic.std.detach().mean())
+                        if keys:
+                            snap_dev[kSnap:kSnap + len(keys)].copy_(ep_stats)
+                        sl[0].copy_(snap_dev, non_blocking=True)
+                    sl[3].record()
+                    pending.append([it, sl, keys, ep_n, None])
+                    # a checkpoint must hold the state after ITS iteration: drain before the next one is enqueued; else lag by one iteration
+                    drain(upto_all=(log and it % self.save_interval == 0) or it == tot_iter - 1)
+                    continue
+                mean_value_loss, mean_surrogate_loss = alg.update()
+                kl = getattr(alg, "last_kl", float("nan"))
                 total_time = time.time() - start
-                collection_time = ev0.elapsed_time(ev1) * 1e-3
-            learn_time = max(total_time - collection_time, 0.0)
-            if _world() > 1:
-                dist.all_reduce(fin)
-            if _world() > 1:
-                step_rew = step_rew.clone()     # made under inference_mode above
-                dist.all_reduce(step_rew)
-                step_rew = step_rew / _world()
-            f = fin.tolist() + [float(step_rew)]   # the one host read of episode statistics per iteration
-            emit(it, collection_time, learn_time, mean_value_loss, mean_surrogate_loss, kl, f,
-                 ep_stats.tolist() if (ep_stats is not None and state["ep_keys"]) else None, state["ep_keys"], ep_n,
-                 float(alg.actor_critic.std.detach().mean()), alg.learning_rate)
+                if on_gpu:
+                    torch.cuda.synchronize()
+                    total_time = time.time() - start
+                    collection_time = ev0.elapsed_time(ev1) * 1e-3
+                learn_time = max(total_time - collection_time, 0.0)
+                if _world() > 1:
+                    dist.all_reduce(fin)
+                if _world() > 1:
+                    step_rew = step_rew.clone()     # made under inference_mode above
+                    dist.all_reduce(step_rew)
+                    step_rew = step_rew / _world()
+                f = fin.tolist() + [float(step_rew)]   # the one host read of episode statistics per iteration
+                emit(it, collection_time, learn_time, mean_value_loss, mean_surrogate_loss, kl, f,
+                     ep_stats.tolist() if (ep_stats is not None and state["ep_keys"]) else None, state["ep_keys"], ep_n,
+                     float(alg.actor_critic.std.detach().mean()), alg.learning_rate)
+        finally:
+            try:
+                if pipe and pending:
+                    drain(True)
+            finally:
+                self._drain_all = None
         self.current_learning_iteration += int(num_learning_iterations)
         if log:
             self.save(os.path.join(self.log_dir, f"model_{self.current_learning_iteration}.pt"))
 
     def save(self, path, infos=None):
         fu = getattr(self.alg, "fused_update", None)
+        drain_all, self._drain_all = getattr(self, "_drain_all", None), None      # (re-entered from the drain's own emit(): nothing left to do)
+        if drain_all is not None:
+            try:
+                drain_all()                       # a checkpoint holds the state after every iteration that has been enqueued
+            finally:
+                self._drain_all = drain_all
         if fu is not None:
             fu.publish_step()                     # Adam's step count into the optimizer state that is saved below
         torch.save({"model_state_dict": self.alg.actor_critic.state_dict(), "optimizer_state_dict": self.alg.optimizer.state_dict(),

@@ -63,20 +63,33 @@ def test_fp64_device_algorithm_is_exact(emul, name):
     g = load_golden(name)
     oerr, rerr, flags, serr = teacher_forced(lambda N: emul.EmulEnv(N, double=True), g)
     assert flags == 0
-    assert oerr.max() <= 1e-7 and rerr.max() <= 2e-7   # float32 rounding of the returned tensors only
+    # float32 rounding of the returned tensors only: two fp64 values that agree to 1e-12 can still round to neighbouring floats, so a
+    # reward may be off by ONE float32 ulp of its magnitude (2.4e-7 for the |r| > 2 of a termination step), never more
+    ulp = np.spacing(np.abs(g["rew"][:len(rerr) // g["rew"].shape[1]]).astype(np.float32)).astype(np.float64).reshape(-1)
+    assert oerr.max() <= 1e-7 and (rerr <= np.maximum(2e-7, ulp)).all(), (oerr.max(), rerr.max())
     assert serr < 1e-9
 
 
 @pytest.mark.parametrize("name", SCENARIOS)
-def test_fp32_device_algorithm_within_tolerance(emul, name):
+def test_fp32_device_algorithm_within_tolerance(emul, oracle_mod, name):
     """Stated tolerance (BASELINE north_star): obs/reward within 1e-4 of the reference path, teacher-forced single step.
-    A support-vertex tie on a flat foot (two hull vertices within ~1e-8 m of the same depth) flips the discrete arg-max
-    between precisions and is the one allowed kind of outlier; its frequency is bounded here."""
+    An env-step above it is accepted only the way the -m gpu tests accept it (tests/test_gpu_parity.py): the ORACLE must show a discrete
+    collision decision (support-vertex tie on a flat foot, contact on / off, extra contact on / off, the 0.3 rbound rule) within 2e-7 m of
+    flipping at that very pre-step state, the error must stay under the bound of that kind of event, and such steps must stay rare."""
+    import parity_tools as pt
     g = load_golden(name)
     oerr, rerr, flags, _ = teacher_forced(lambda N: emul.EmulEnv(N, double=False), g)
     assert flags == 0
-    n_out = int((oerr > 1e-4).sum())
-    assert n_out <= max(1, len(oerr) // 500), (n_out, len(oerr))
+    N = g["actions"].shape[1]
+    bounds = {"tie": 2e-2, "nbr": 2e-2, "tol": 2e-2, "act": 1e-1}
+    outliers = np.nonzero(oerr > 1e-4)[0]
+    for k in outliers:
+        t, i = divmod(int(k), N)
+        pre = {n: (g["init_" + n][i] if t == 0 else g[n][t - 1][i]) for n in ("qpos", "qvel", "qacc_warmstart", "dof_pos")}
+        m, kind, npair = pt.discrete_margin(oracle_mod, pre["qpos"], pre["qvel"], pre["qacc_warmstart"], pt.servo_ctrl(g["actions"][t][i], pre["dof_pos"]))
+        assert npair == 0 and m < 2e-7 and oerr[k] <= bounds.get(kind, 0.0), \
+            f"{name} step {t} env {i}: error {oerr[k]:.2e} above 1e-4 at a state whose nearest discrete decision is {m:.2e} m away ({kind})"
+    assert len(outliers) <= max(2, len(oerr) // 200), (len(outliers), len(oerr))
     assert np.percentile(oerr, 99) < 2e-5 and np.median(oerr) < 2e-6
     assert np.percentile(rerr, 99) < 2e-5
 

@@ -284,6 +284,65 @@ def test_row_gather_inside_the_kernel_equals_the_gathered_copy_and_the_fused_ste
         torch.testing.assert_close(fus[1].m, fus[2].m, atol=1e-9, rtol=2e-6)
 
 
+def test_a_failed_grid_barrier_makes_the_fused_step_a_no_op_and_is_reported():
+    """k_ppo_step synchronises its ~236 workgroups with a spinning grid barrier. (a) nm_ppo_create asks the runtime
+    whether that grid is co-resident (occupancy x CUs) - on a whole MI355X it is, so the handle takes the fused step. (b) When the barrier
+    does time out (forced here by the test hook: the arrival counter is moved out of reach), the step is a NO-OP for every block - no
+    parameter, Adam moment or packed weight is written, the Adam step counter does not advance - and stays one until the failure has been
+    reported; nm_ppo_get_state then fails loudly, re-arms the barrier and moves the handle to the four-launch step, which works."""
+    import copy
+    from nightmare_rl_amd import _lib
+    from nightmare_rl_amd.rl import ActorCritic
+    from nightmare_rl_amd.rl.fused import FusedUpdate
+    torch.manual_seed(4)
+    ac = ActorCritic(66, 66, 18, actor_hidden_dims=[54, 42, 30], critic_hidden_dims=[54, 42, 30], activation="elu", init_noise_std=0.8).to(DEV)
+    ref = copy.deepcopy(ac)
+    fu = FusedUpdate(ac, torch.optim.Adam(ac.parameters(), lr=1e-3), DEV, lr=1e-3)
+    fr = FusedUpdate(ref, torch.optim.Adam(ref.parameters(), lr=1e-3), DEV, lr=1e-3)
+    L = _lib.load()
+    assert L.nm_ppo_step_is_fused(fu._h) == 1                      # the occupancy query of nm_ppo_create found room for the whole grid
+    hp = dict(clip=0.2, value_coef=1.0, entropy_coef=0.0015, clip_value=True, desired_kl=0.01, adaptive=True, max_grad_norm=1.0)
+    R = 4096
+    gen = torch.Generator(device=DEV).manual_seed(9)
+    rn = lambda *s: torch.randn(*s, device=DEV, generator=gen)
+    obs = rn(R, 66)
+    with torch.no_grad():
+        old_mu = ac.actor(obs) + 0.05 * rn(R, 18)
+        old_sigma = ac.std.expand(R, 18).contiguous()
+        actions = old_mu + old_sigma * rn(R, 18)
+        old_logp = torch.distributions.Normal(old_mu, old_sigma).log_prob(actions).sum(-1)
+        tv = ac.critic(obs).squeeze(-1) + 0.3 * rn(R)
+    batch = (obs, actions, tv, rn(R), tv + rn(R), old_logp, old_mu, old_sigma)
+    fu.minibatch(*batch, hp)
+    fr.minibatch(*batch, hp)
+    s_ok = fu.read_state()
+    assert torch.equal(fu.flat, fr.flat) and s_ok["steps"] == 1.0
+    before = (fu.flat.clone(), fu.m.clone(), fu.v.clone())
+    stream = C.c_void_p(torch.cuda.current_stream(torch.device(DEV)).cuda_stream)
+    _lib.check(L.nm_ppo_debug_break_barrier(fu._h, stream))
+    fu.minibatch(*batch, hp)                                       # its barrier times out: a no-op
+    fu.minibatch(*batch, hp)                                       # sticky: returns at the barrier without arriving
+    torch.cuda.synchronize()
+    assert torch.equal(fu.flat, before[0]) and torch.equal(fu.m, before[1]) and torch.equal(fu.v, before[2])
+    snap = torch.zeros(16, device=DEV)
+    fu.snapshot_state(snap[:9])
+    vals = snap[:9].tolist()
+    assert vals[8] != 0.0 and vals[1] == 1.0                       # flagged; Adam's step count did not move
+    with pytest.raises(_lib.NightmareHipError, match="grid barrier"):
+        fu.state_from(vals)
+    fu.minibatch(*batch, hp)                                       # still refused after a snapshot (the snapshot clears only the flag)
+    with pytest.raises(_lib.NightmareHipError, match="grid barrier"):
+        fu.read_state()
+    assert torch.equal(fu.flat, before[0])
+    assert L.nm_ppo_step_is_fused(fu._h) == 0                      # reported -> barrier re-armed, handle on the four-launch step
+    fu.step_count = 1
+    fu.minibatch(*batch, hp)
+    fr.minibatch(*batch, hp)
+    s2, r2 = fu.read_state(), fr.read_state()
+    assert s2["steps"] == r2["steps"] == 2.0 and s2["lr"] == r2["lr"]
+    torch.testing.assert_close(fu.flat, fr.flat, atol=1e-7, rtol=2e-6)          # four launches vs one: rounding of the norm sum
+
+
 def test_learning_curve_at_4096_envs_lies_inside_the_cpu_reference_band():
     """BASELINE config 5's 'return curve vs CPU ref' as an assertion: the runner on the HIP env (fp32 kernels, one-launch rollout, fused
     update) for 25 iterations at 4096 envs against the band the SAME runner reached on the CPU oracle env (fp64, torch PPO; 3 seeds,

@@ -179,3 +179,28 @@ def test_self_launch_starts_the_ranks_as_children_and_relays_status(tmp_path):
         r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"], env=env,
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 2 and "HIP device(s) visible" in r.stderr
+
+
+def test_gpu_count_for_the_launching_parent_comes_from_sysfs_not_from_torch_cuda(tmp_path):
+    """the parent of a multi-rank job counts devices without a HIP call - KFD topology nodes with SIMDs whose render
+    node this process can open, narrowed by the *_VISIBLE_DEVICES variables - and nothing on the launch path touches torch.cuda."""
+    import inspect
+    import re
+
+    from nightmare_rl_amd import distributed as D
+    topo, dri = tmp_path / "nodes", tmp_path / "dri"
+    dri.mkdir()
+    for i, (simd, minor) in enumerate([(0, -1), (0, -1), (1024, 128), (1024, 129), (1024, 130)]):      # two CPU nodes, three GPUs
+        (topo / str(i)).mkdir(parents=True)
+        (topo / str(i) / "properties").write_text(f"cpu_cores_count {0 if simd else 64}\nsimd_count {simd}\ndrm_render_minor {minor}\n")
+    for minor in (128, 129):                          # the container was handed two of the three cards
+        (dri / f"renderD{minor}").write_text("")
+    assert D.count_gpus_sysfs(str(topo), str(dri), env={}) == 2
+    assert D.count_gpus_sysfs(str(topo), str(dri), env={"HIP_VISIBLE_DEVICES": "0"}) == 1
+    assert D.count_gpus_sysfs(str(topo), str(dri), env={"HIP_VISIBLE_DEVICES": ""}) == 0
+    assert D.count_gpus_sysfs(str(topo), str(dri), env={"ROCR_VISIBLE_DEVICES": "0,1,2", "CUDA_VISIBLE_DEVICES": "1,-1,0"}) == 1
+    assert D.count_gpus_sysfs(str(tmp_path / "absent"), str(dri), env={}) is None       # no amdgpu driver: the caller asks a child process
+    assert D.count_gpus_in_child() == torch.cuda.device_count()                          # the fallback agrees with torch (0 in the build container)
+    for fn in (D.self_launch, D.count_gpus, D.count_gpus_sysfs):
+        code = re.sub(r'""".*?"""', "", inspect.getsource(fn), flags=re.S)               # the docstrings may name it, the code may not
+        assert "torch.cuda" not in code and "import torch" not in code.replace('"import torch;', "")
