@@ -1315,31 +1315,59 @@ template <int C, int N, class F> NM_FN void for_contacts(int ncon, F&& f) {
     }
   }
 }
+// f(0) .. f(3) with compile-time indices (the four pyramid rows of a contact)
+template <class F> NM_FN void sfor4(F&& f) {
+  f(std::integral_constant<int, 0>{}); f(std::integral_constant<int, 1>{}); f(std::integral_constant<int, 2>{}); f(std::integral_constant<int, 3>{});
+}
+// f(0), f(1), ... over the pyramid pairs of the first ncon contacts (two pairs per contact), compile-time indices, one uniform test per contact
+template <int NP, int P = 0, class F> NM_FN void sfor_pairs(int ncon, F&& f) {
+  if constexpr (P < NP) {
+    if (P / 2 < ncon) {
+      f(std::integral_constant<int, P>{});
+      f(std::integral_constant<int, P + 1>{});
+      sfor_pairs<NP, P + 2>(ncon, f);
+    }
+  }
+}
+// compile-time lane masks of the row layouts (sel_lanes): row i of a one-env wave is lane i; of the two-env pass lanes i and 32 + i;
+// pair p = the two lanes 2p, 2p + 1 (in both halves)
+template <int I> struct Row1Mask { static constexpr uint32_t lo = I < 32 ? (1u << (I & 31)) : 0u, hi = I >= 32 ? (1u << (I & 31)) : 0u; };
+template <int P> struct Pair1Mask { static constexpr uint32_t lo = 2 * P < 32 ? (3u << ((2 * P) & 31)) : 0u, hi = 2 * P >= 32 ? (3u << ((2 * P) & 31)) : 0u; };
+template <int I> struct Row2Mask { static constexpr uint32_t lo = 1u << I, hi = 1u << I; };
+template <int P> struct Pair2Mask { static constexpr uint32_t lo = 3u << (2 * P), hi = 3u << (2 * P); };
 // ---- The two update rules of the constraint solver, stated ONCE. The three row layouts below (row per lane on 64 lanes, two envs on
 // half-waves, matrix-free rows in three slots per lane) differ in how a row's delta reaches the other rows' residuals - a v_readlane
 // broadcast into a register-resident A row, two of them under the halves' masks, a block-factor solve through LDS - not in these
 // formulas; a change to either rule is made here and nowhere else.
 // mj_solPGS (engine_solver.c), one row of a pyramidal contact: residual res = (A f + b)_i + R_i f_i with the CURRENT forces, projected
-// coordinate step f_i <- max(f_i - res / (A_ii + R_i), 0); returns the delta, leaves the residual in `res` (the row's cost change needs it)
-template <class X> NM_FN X pgs_row_delta(const X& g, const X& Rr, const X& f, const X& ARinv, X& res) {
-  res = g + Rr * f;
-  return vmax(-res * ARinv, -f);              // = max(f - res/AR_ii, 0) - f
+// coordinate step f_i <- max(f_i - res / (A_ii + R_i), 0), i.e. delta = max(-(g + R f) / AR, -f) with g = (A f + b)_i. A row is updated once
+// per sweep and its force only changes at its own step, so everything but g is constant over a sweep: k0 = -1 / AR, k1 = -(R f) / AR,
+// nf = -f are prepared per sweep (round 5: the sweeps are VALU-ISSUE bound - scripts/micro/pgs_chain.hip: a row update costs its
+// instruction count x 4.6 ticks whatever the dependences - so the rule is written for the fewest instructions per row: one fma + one max).
+// A row that must not move any more (two-env pass: its half has met the tolerance) gets k0 = k1 = nf = 0: delta = max(0, 0) = 0.
+template <class X> NM_FN void pgs_row_prepare(const X& Rr, const X& f, const X& ARinv, X& k0, X& k1, X& nf) {
+  k0 = -ARinv;
+  k1 = (Rr * f) * k0;
+  nf = -f;
 }
-// ... and its cost change 0.5 dl^2 AR_ii + dl res (hA = 0.5 AR_ii): what mj_solPGS sums for the tolerance exit
-template <class X> NM_FN X pgs_row_cost(const X& dl, const X& hA, const X& res) { return dl * (hA * dl + res); }
+template <class X> NM_FN X pgs_row_delta(const X& g, const X& k0, const X& k1, const X& nf) { return vmax(vfma(g, k0, k1), nf); }
+// ... and its cost change 0.5 dl^2 AR_ii + dl res (hA = 0.5 AR_ii; res = g + R f with the g the row saw at its own step): what mj_solPGS
+// sums for the tolerance exit
+template <class X> NM_FN X pgs_row_cost(const X& dl, const X& hA, const X& g, const X& Rr, const X& f) { return dl * vfma(hA, dl, vfma(Rr, f, g)); }
 // mj_solNoSlip (engine_solver.c), one opposing pyramid pair seen from ONE of its two rows (f, g = own force and residual without R; fp, gp =
-// the partner's): exact 1-D minimisation along (f - fp) - a Newton step on the difference of the two residuals (K1 = A00 + A11 - 2 A01,
-// invK1 = 1 / K1, hK1 = 0.5 K1), clamped so that both forces stay non-negative (their sum is kept); a degenerate pair (K1 < 1e-15) goes to
-// its mean. `change` = the pair's cost change d (0.5 K1 d + dg), `bad` = mj_solNoSlip's revert test (change > 1e-10): the caller drops d then.
-template <class real, class X, class B> NM_FN X noslip_pair_delta(const X& g, const X& gp, const X& f, const X& fp, const X& invK1, const X& hK1, const B& small,
-                                                                    X& change, B& bad) {
-  const X dg = g - gp;
-  X d = vmin(vmax(-dg * invK1, -f), fp);
-  d = sel(small, real(0.5) * (fp - f), d);
-  change = d * (hK1 * d + dg);
-  bad = change > X(real(1e-10));     // costChange: revert an update that does not decrease the cost
-  return d;
+// the partner's): exact 1-D minimisation along (f - fp) - a Newton step on the difference dg = g - gp of the two residuals (K1 = A00 + A11 -
+// 2 A01, invK1 = 1 / K1, hK1 = 0.5 K1), clamped to [lo, hi] = [-f, fp] so that both forces stay non-negative (their sum is kept); a
+// degenerate pair (K1 < 1e-15) goes to its mean: lo = hi = 0.5 (fp - f). The bounds are constant over a sweep (prepared once per sweep; a
+// pair that must not move gets lo = hi = 0). cost change of the pair = d (0.5 K1 d + dg); mj_solNoSlip reverts an update whose cost change
+// exceeds 1e-10 (`noslip_pair_bad`): the caller drops d then.
+template <class real, class X, class B> NM_FN void noslip_pair_prepare(const X& f, const X& fp, const B& small, X& lo, X& hi) {
+  const X mean = real(0.5) * (fp - f);
+  lo = sel(small, mean, -f);
+  hi = sel(small, mean, fp);
 }
+template <class X> NM_FN X noslip_pair_delta(const X& dg, const X& invK1, const X& lo, const X& hi) { return vmin(vmax(-dg * invK1, lo), hi); }
+template <class X> NM_FN X noslip_pair_cost(const X& d, const X& hK1, const X& dg) { return d * vfma(hK1, d, dg); }
+template <class real, class X> NM_FN auto noslip_pair_bad(const X& change) { return change > X(real(1e-10)); }   // costChange: revert an update that does not decrease the cost
 
 // Contact rows on lanes: build, project (A = J M^-1 J'), warm start, PGS, NoSlip, map back, sensors.
 template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, real* jrow, const Model<real>& M, bool last, bool nosweep) {
@@ -1599,28 +1627,26 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   // Per row: all lanes evaluate their own candidate, lane i's delta is broadcast (v_readlane) and applied.
   const vr hA = real(0.5) * ARjj;
   for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
-    // A row's update is decided by its own lane at its own step: the lane keeps (delta, cost change) and applies them to
-    // f after the sweep; the other lanes only need the delta, which reaches them through g.
-    vr dcap = vr(real(0)), rcap = vr(real(0));
-    const V<int> lv = opaque_lane();
+    // A row's update is decided by its own lane at its own step: the lane keeps the residual it saw there (one select under a literal lane
+    // mask) and forms its delta and cost change from it after the sweep; the other lanes only need the delta, which reaches them through g.
+    vr k0, k1, nf;
+    pgs_row_prepare(Rr, f, ARinv, k0, k1, nf);
+    vr gcap = g;
     for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
       constexpr int cc = decltype(ccT)::value;
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int i = 4 * cc + r;
-        vr res;
-        vr dl = pgs_row_delta(g, Rr, f, ARinv, res);
-        g += A[i] * rdlane(dl, i);
-        VB me = lv == i;
-        dcap = sel(me, dl, dcap);
-        rcap = sel(me, res, rcap);                   // the residual the row saw at its own step
-      }
+      sfor4([&](auto rT) {
+        constexpr int i = 4 * cc + decltype(rT)::value;
+        gcap = sel_lanes<Row1Mask<i>::lo, Row1Mask<i>::hi>(g, gcap);
+        const vr dl = pgs_row_delta(g, k0, k1, nf);
+        g = vfma(A[i], vr(rdlane(dl, i)), g);
+      });
     });
     // cost change of a row, 0.5 dl^2 AR_ii + dl res, formed once after the sweep from what the lane kept. mj_solPGS reverts an update
     // whose cost change exceeds +1e-10; for this projected coordinate step that cannot happen: unclamped, 0.5 AR dl + res =
     // res (1 - 0.5 AR/AR~) has the sign of res = -sign(dl); clamped at zero, res >= AR f makes it -f (res - 0.5 AR f) <= 0 - no
     // cancellation in either case, so no test.
-    const vr ccap = pgs_row_cost(dcap, hA, rcap);
+    const vr dcap = pgs_row_delta(gcap, k0, k1, nf);
+    const vr ccap = pgs_row_cost(dcap, hA, gcap, Rr, f);
     f = f + dcap;
     sh.it_pgs = iter + 1;
     if (-wsum<real>(ccap) * M.pgs_scale < M.pgs_tol) break;
@@ -1635,7 +1661,6 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
   // evaluates its side with the partner's (f, g) from DPP; 1/K1 and 0.5 K1 are prepared once.
   {
     const V<int> lv = opaque_lane();
-    const V<int> lvp = lv >> 1;
     const VB even = (lv & 1) == 0;
     vr Amq = vr(real(0));  // A[2p][2p+1], the even lane's copy in both lanes
     for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
@@ -1658,23 +1683,20 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       real improvement = real(0);
       if (iter == 0) improvement = wsum<real>(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
-      vr dcap = vr(real(0)), ccap = vr(real(0));
-#pragma unroll
-      for (int p = 0; p < kMaxRow / 2; p++) {
-        if ((p & 1) == 0 && !(p / 2 < ncon)) break;   // one uniform test per contact (two pairs)
-        {
-          vr change;
-          VB bad;
-          vr d = noslip_pair_delta<real>(g, shfl_xor1(g), f, shfl_xor1(f), invK1, hK1, small, change, bad);
-          d = sel(bad, vr(real(0)), d);
-          g += A[2 * p] * rdlane(d, 2 * p);
-          const VB me = lvp == p;
-          dcap = sel(me, d, dcap);
-          ccap = sel(me & even & !bad, change, ccap);
-        }
-      }
+      vr lo, hi;
+      noslip_pair_prepare<real>(f, shfl_xor1(f), small, lo, hi);
+      vr dcap = vr(real(0)), dgcap = vr(real(0));      // a pair keeps its step and the residual difference it saw: the cost change is formed after the sweep
+      sfor_pairs<kMaxRow / 2>(ncon, [&](auto pT) {
+        constexpr int p = decltype(pT)::value;
+        const vr dg = g - shfl_xor1(g);
+        vr d = noslip_pair_delta(dg, invK1, lo, hi);
+        d = sel(noslip_pair_bad<real>(noslip_pair_cost(d, hK1, dg)), vr(real(0)), d);
+        g = vfma(A[2 * p], vr(rdlane(d, 2 * p)), g);
+        dcap = sel_lanes<Pair1Mask<p>::lo, Pair1Mask<p>::hi>(d, dcap);
+        dgcap = sel_lanes<Pair1Mask<p>::lo, Pair1Mask<p>::hi>(dg, dgcap);
+      });
       f = f + dcap;
-      improvement = improvement - wsum<real>(ccap);
+      improvement = improvement - wsum<real>(sel(even, noslip_pair_cost(dcap, hK1, dgcap), vr(real(0))));     // a reverted pair kept d = 0: no change
       sh.it_noslip = iter + 1;
       if (improvement * M.pgs_scale < M.noslip_tol) break;
     }
@@ -1967,23 +1989,21 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   {
     VB run = VB(true);
     for (int iter = 0; iter < (nosweep ? 0 : M.pgs_iters); iter++) {
-      vr dcap = vr(real(0)), rcap = vr(real(0));
-      const V<int> lv = opaque_lane() & 31;
+      vr k0, k1, nf;
+      pgs_row_prepare(Rr, f, ARinv, k0, k1, nf);
+      k0 = sel(run, k0, vr(real(0))); k1 = sel(run, k1, vr(real(0))); nf = sel(run, nf, vr(real(0)));      // a half that has met its tolerance stands still
+      vr gcap = g;
       for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
         constexpr int cc = decltype(ccT)::value;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = 4 * cc + r;
-          vr res;
-          vr dl = pgs_row_delta(g, Rr, f, ARinv, res);
-          dl = sel(run, dl, vr(real(0)));
-          g += A[i] * RDL(dl, i);
-          VB me = lv == i;
-          dcap = sel(me, dl, dcap);
-          rcap = sel(me, res, rcap);       // the residual this row saw at its own step: its cost change is formed once, after the sweep
-        }
+        sfor4([&](auto rT) {
+          constexpr int i = 4 * cc + decltype(rT)::value;
+          gcap = sel_lanes<Row2Mask<i>::lo, Row2Mask<i>::hi>(g, gcap);       // the residual this row sees at its own step
+          const vr dl = pgs_row_delta(g, k0, k1, nf);
+          g = vfma(A[i], RDL(dl, i), g);
+        });
       });
-      const vr ccap = pgs_row_cost(dcap, hA, rcap);
+      const vr dcap = pgs_row_delta(gcap, k0, k1, nf);
+      const vr ccap = pgs_row_cost(dcap, hA, gcap, Rr, f);
       f = f + dcap;
       itp = itp + sel(run, V<int>(1), V<int>(0));
       run = run & !((-hsum32(ccap)) * M.pgs_scale < vr(M.pgs_tol));
@@ -1994,7 +2014,6 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   // ---- mj_solNoSlip
   {
     const V<int> lv = opaque_lane() & 31;
-    const V<int> lvp = lv >> 1;
     const VB even = (lv & 1) == 0;
     vr Amq = vr(real(0));
     for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
@@ -2015,23 +2034,21 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       vr improvement = vr(real(0));
       if (iter == 0) improvement = hsum32(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
-      vr dcap = vr(real(0)), ccap = vr(real(0));
-#pragma unroll
-      for (int p = 0; p < kMaxRow2 / 2; p++) {
-        if ((p & 1) == 0 && !(p / 2 < nmax)) break;   // one uniform test per contact (two pairs)
-        {
-          vr change;
-          VB bad;
-          vr d = noslip_pair_delta<real>(g, shfl_xor1(g), f, shfl_xor1(f), invK1, hK1, small, change, bad);
-          d = sel(bad | !run, vr(real(0)), d);
-          g += A[2 * p] * RDL(d, 2 * p);
-          const VB me = lvp == p;
-          dcap = sel(me, d, dcap);
-          ccap = sel(me & even & !bad & run, change, ccap);
-        }
-      }
+      vr lo, hi;
+      noslip_pair_prepare<real>(f, shfl_xor1(f), small, lo, hi);
+      lo = sel(run, lo, vr(real(0))); hi = sel(run, hi, vr(real(0)));
+      vr dcap = vr(real(0)), dgcap = vr(real(0));
+      sfor_pairs<kMaxRow2 / 2>(nmax, [&](auto pT) {
+        constexpr int p = decltype(pT)::value;
+        const vr dg = g - shfl_xor1(g);
+        vr d = noslip_pair_delta(dg, invK1, lo, hi);
+        d = sel(noslip_pair_bad<real>(noslip_pair_cost(d, hK1, dg)), vr(real(0)), d);
+        g = vfma(A[2 * p], RDL(d, 2 * p), g);
+        dcap = sel_lanes<Pair2Mask<p>::lo, Pair2Mask<p>::hi>(d, dcap);
+        dgcap = sel_lanes<Pair2Mask<p>::lo, Pair2Mask<p>::hi>(dg, dgcap);
+      });
       f = f + dcap;
-      improvement = improvement - hsum32(ccap);
+      improvement = improvement - hsum32(sel(even, noslip_pair_cost(dcap, hK1, dgcap), vr(real(0))));
       itn = itn + sel(run, V<int>(1), V<int>(0));
       run = run & !(improvement * M.pgs_scale < vr(M.noslip_tol));
       if (!wany(run)) break;
@@ -2367,9 +2384,11 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
     for (int k = 0; k < kBigSlots; k++) {
       for (int ln = 0; ln < NM_WAVE; ln++) {
         if (NM_WAVE * k + ln >= nefc) break;
-        vr res;
-        const vr dl = pgs_row_delta(big_residual(sh, r, k), r.Rr[k], r.f[k], r.ARinv[k], res);
-        const vr change = pgs_row_cost(dl, r.hA[k], res);
+        vr k0, k1, nf;
+        pgs_row_prepare(r.Rr[k], r.f[k], r.ARinv[k], k0, k1, nf);
+        const vr gk = big_residual(sh, r, k);
+        const vr dl = pgs_row_delta(gk, k0, k1, nf);
+        const vr change = pgs_row_cost(dl, r.hA[k], gk, r.Rr[k], r.f[k]);
         const real d = rdlane(dl, ln);
         improvement -= rdlane(change, ln);
         r.f[k] = sel(lane == ln, r.f[k] + dl, r.f[k]);
@@ -2398,9 +2417,12 @@ template <class real> NM_COLD void stage_constraint_big(Sh<real>& sh, const Mode
       for (int pp = 0; pp < NM_WAVE / 2; pp++) {
         if (NM_WAVE * k + 2 * pp >= nefc) break;
         const vr g = big_residual(sh, r, k);
-        vr change;
-        VB bad;
-        vr d = noslip_pair_delta<real>(g, shfl_xor1(g), r.f[k], shfl_xor1(r.f[k]), r.invK1[k], r.hK1[k], r.small[k], change, bad);
+        vr lo, hi;
+        noslip_pair_prepare<real>(r.f[k], shfl_xor1(r.f[k]), r.small[k], lo, hi);
+        const vr dg = g - shfl_xor1(g);
+        vr d = noslip_pair_delta(dg, r.invK1[k], lo, hi);
+        const vr change = noslip_pair_cost(d, r.hK1[k], dg);
+        const VB bad = noslip_pair_bad<real>(change);
         d = sel(bad, vr(real(0)), d);
         const real d0 = rdlane(d, 2 * pp), d1 = rdlane(d, 2 * pp + 1);
         improvement -= rdlane(sel(bad, vr(real(0)), change), 2 * pp);

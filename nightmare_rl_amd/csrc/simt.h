@@ -78,6 +78,24 @@ template <class T, class S> NM_FN T vcvt(S x) { return (T)x; }   // per-lane val
 NM_FN float vrcp(float x) { return __builtin_amdgcn_rcpf(x); }
 NM_FN double vrcp(double x) { return 1.0 / x; }
 
+// a * b + c in ONE rounding, wherever it is written (the solver's update rules are stated once and must give the same bits in every
+// row layout: the contraction is not left to the compiler's mood)
+NM_FN float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+NM_FN double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// a in the lanes of the compile-time mask (LO: lanes 0..31, HI: lanes 32..63), b elsewhere. The mask is a literal in two scalar moves
+// (SALU, not a VALU slot) instead of a v_cmp against the lane id per use: the solver sweeps keep one value per row at that row's own
+// step, i.e. one of these per row and sweep - and 64 loop-invariant compare masks would not fit the scalar register file.
+template <uint32_t LO, uint32_t HI> NM_FN float sel_lanes(float a, float b) {
+  float r;
+  asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(r) : "v"(b), "v"(a), "n"(LO), "n"(HI) : "vcc");
+  return r;
+}
+template <uint32_t LO, uint32_t HI> NM_FN double sel_lanes(double a, double b) {
+  int rl, rh;
+  asm("s_mov_b32 vcc_lo, %5\n\ts_mov_b32 vcc_hi, %6\n\tv_cndmask_b32_e32 %0, %2, %3, vcc\n\tv_cndmask_b32_e32 %1, %4, %7, vcc"
+      : "=&v"(rl), "=v"(rh) : "v"(__double2loint(b)), "v"(__double2loint(a)), "v"(__double2hiint(b)), "n"(LO), "n"(HI), "v"(__double2hiint(a)) : "vcc");
+  return __hiloint2double(rh, rl);
+}
 // value of lane l (l wave-uniform) as a wave-uniform scalar
 NM_FN int rdlane(int x, int l) { return __builtin_amdgcn_readlane(x, l); }
 NM_FN float rdlane(float x, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), l)); }
@@ -283,6 +301,14 @@ NM_FN float vrcp(float x) { return 1.0f / x; }
 NM_FN double vrcp(double x) { return 1.0 / x; }
 template <class T, class S> NM_FN V<T> vcvt(const V<S>& a) { V<T> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (T)a.v[i]; return r; }
 
+template <class T> NM_FN V<T> vfma(const V<T>& a, const V<T>& b, const V<T>& c) { return a * b + c; }      // (the host build is compiled with -ffp-contract=off: two roundings, everywhere)
+NM_FN float vfma(float a, float b, float c) { return a * b + c; }
+NM_FN double vfma(double a, double b, double c) { return a * b + c; }
+template <uint32_t LO, uint32_t HI, class T> NM_FN V<T> sel_lanes(const V<T>& a, const V<T>& b) {
+  V<T> r;
+  for (int i = 0; i < NM_WAVE; i++) r.v[i] = ((i < 32 ? LO >> i : HI >> (i - 32)) & 1u) ? a.v[i] : b.v[i];
+  return r;
+}
 template <class T> NM_FN T rdlane(const V<T>& x, int l) { return x.v[l]; }
 template <class T> NM_FN T rdlane(T x, int) { return x; }
 template <class T> NM_FN V<T> wrlane(V<T> x, T v, int l) { x.v[l] = v; return x; }

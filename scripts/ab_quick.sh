@@ -1,0 +1,8 @@
+set -e
+for rep in 1 2; do
+  for lib in base ""; do
+    L=nightmare_rl_amd/csrc/libnightmare_hip${lib:+_$lib}.so
+    NM_HIP_LIB=$PWD/$L python scripts/quickbench.py 4096 0 1.0 2>&1 | grep "step kernel"
+    NM_HIP_LIB=$PWD/$L python scripts/quickbench.py 4096 0 0.12 2>&1 | grep "step kernel"
+  done
+done
