@@ -1632,11 +1632,13 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
     vr k0, k1, nf;
     pgs_row_prepare(Rr, f, ARinv, k0, k1, nf);
     vr gcap = g;
+    uint64_t rowm = mask_shl(1ull, 0);                        // lane mask of the row whose turn it is: shifted along with the sweep
     for_contacts<0, kMaxCon>(ncon, [&](auto ccT) {
       constexpr int cc = decltype(ccT)::value;
       sfor4([&](auto rT) {
         constexpr int i = 4 * cc + decltype(rT)::value;
-        gcap = sel_lanes<Row1Mask<i>::lo, Row1Mask<i>::hi>(g, gcap);
+        gcap = sel_mask(rowm, g, gcap);
+        rowm = mask_shl(rowm, 1);
         const vr dl = pgs_row_delta(g, k0, k1, nf);
         g = vfma(A[i], vr(rdlane(dl, i)), g);
       });
@@ -1686,14 +1688,16 @@ template <class real, bool PAIR> NM_FN void stage_constraint_body(Sh<real>& sh, 
       vr lo, hi;
       noslip_pair_prepare<real>(f, shfl_xor1(f), small, lo, hi);
       vr dcap = vr(real(0)), dgcap = vr(real(0));      // a pair keeps its step and the residual difference it saw: the cost change is formed after the sweep
+      uint64_t pairm = mask_shl(3ull, 0);
       sfor_pairs<kMaxRow / 2>(ncon, [&](auto pT) {
         constexpr int p = decltype(pT)::value;
         const vr dg = g - shfl_xor1(g);
         vr d = noslip_pair_delta(dg, invK1, lo, hi);
         d = sel(noslip_pair_bad<real>(noslip_pair_cost(d, hK1, dg)), vr(real(0)), d);
         g = vfma(A[2 * p], vr(rdlane(d, 2 * p)), g);
-        dcap = sel_lanes<Pair1Mask<p>::lo, Pair1Mask<p>::hi>(d, dcap);
-        dgcap = sel_lanes<Pair1Mask<p>::lo, Pair1Mask<p>::hi>(dg, dgcap);
+        dcap = sel_mask(pairm, d, dcap);
+        dgcap = sel_mask(pairm, dg, dgcap);
+        pairm = mask_shl(pairm, 2);
       });
       f = f + dcap;
       improvement = improvement - wsum<real>(sel(even, noslip_pair_cost(dcap, hK1, dgcap), vr(real(0))));     // a reverted pair kept d = 0: no change
@@ -1815,7 +1819,6 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   const int oCleg = (int)((offsetof(Sh<real>, legtmp) + 7 * kMaxConBig * sizeof(real)) / sizeof(int));
 #define SHR(field, idx) ldsv(rb, ho + ((idx) + NM_OFS(field)))
 #define SHI(field, idx) ldsv(ib, hoi + ((idx) + NM_IOFS(field)))
-#define RDL(x, i) sel(h1, vr(rdlane(x, kMaxRow2 + (i))), vr(rdlane(x, (i))))
   const int n0 = uniform(w.e[0].ncon), n1 = uniform(w.e[1].ncon), nmax = vmax(n0, n1);
   const V<int> nconv = sel(h1, V<int>(n1), V<int>(n0)), nefc = nconv * 4;
   const VB act = hl < nefc;
@@ -1974,8 +1977,7 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   vr g = bb;
   for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
     constexpr int cc = decltype(ccT)::value;
-#pragma unroll
-    for (int r = 0; r < 4; r++) g += A[4 * cc + r] * RDL(f, 4 * cc + r);
+    sfor4([&](auto rT) { constexpr int i = 4 * cc + decltype(rT)::value; g = fma_half_lane<i>(A[i], f, g, h1); });
   });
   {
     const vr cost = hsum32(sel(act, f * (bb + real(0.5) * (g - bb + Rr * f)), vr(real(0))));
@@ -1993,13 +1995,15 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
       pgs_row_prepare(Rr, f, ARinv, k0, k1, nf);
       k0 = sel(run, k0, vr(real(0))); k1 = sel(run, k1, vr(real(0))); nf = sel(run, nf, vr(real(0)));      // a half that has met its tolerance stands still
       vr gcap = g;
+      uint64_t rowm = mask_shl(0x0000000100000001ull, 0);     // lanes i and 32 + i of the row whose turn it is
       for_contacts<0, kMaxCon2>(nmax, [&](auto ccT) {
         constexpr int cc = decltype(ccT)::value;
         sfor4([&](auto rT) {
           constexpr int i = 4 * cc + decltype(rT)::value;
-          gcap = sel_lanes<Row2Mask<i>::lo, Row2Mask<i>::hi>(g, gcap);       // the residual this row sees at its own step
+          gcap = sel_mask(rowm, g, gcap);        // the residual this row sees at its own step
+          rowm = mask_shl(rowm, 1);
           const vr dl = pgs_row_delta(g, k0, k1, nf);
-          g = vfma(A[i], RDL(dl, i), g);
+          g = fma_half_lane<i>(A[i], dl, g, h1);
         });
       });
       const vr dcap = pgs_row_delta(gcap, k0, k1, nf);
@@ -2038,14 +2042,16 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
       noslip_pair_prepare<real>(f, shfl_xor1(f), small, lo, hi);
       lo = sel(run, lo, vr(real(0))); hi = sel(run, hi, vr(real(0)));
       vr dcap = vr(real(0)), dgcap = vr(real(0));
+      uint64_t pairm = mask_shl(0x0000000300000003ull, 0);
       sfor_pairs<kMaxRow2 / 2>(nmax, [&](auto pT) {
         constexpr int p = decltype(pT)::value;
         const vr dg = g - shfl_xor1(g);
         vr d = noslip_pair_delta(dg, invK1, lo, hi);
         d = sel(noslip_pair_bad<real>(noslip_pair_cost(d, hK1, dg)), vr(real(0)), d);
-        g = vfma(A[2 * p], RDL(d, 2 * p), g);
-        dcap = sel_lanes<Pair2Mask<p>::lo, Pair2Mask<p>::hi>(d, dcap);
-        dgcap = sel_lanes<Pair2Mask<p>::lo, Pair2Mask<p>::hi>(dg, dgcap);
+        g = fma_half_lane<2 * p>(A[2 * p], d, g, h1);
+        dcap = sel_mask(pairm, d, dcap);
+        dgcap = sel_mask(pairm, dg, dgcap);
+        pairm = mask_shl(pairm, 2);
       });
       f = f + dcap;
       improvement = improvement - hsum32(sel(even, noslip_pair_cost(dcap, hK1, dgcap), vr(real(0))));
@@ -2119,7 +2125,6 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
   wave_sync();
 #undef SHR
 #undef SHI
-#undef RDL
 }
 
 // =========================================================================================  stage C beyond kMaxCon contacts

@@ -10,6 +10,8 @@
 //   V5  V1 with the broadcast as ONE ds_bpermute_b32 (LDS crossbar: lane l reads lane (l & 32) + i; no VALU slot, no SGPR round trip) and
 //       the capture of a row's own dl under a literal lane mask in an SGPR pair (no v_cmp): 4 VALU + 1 DS per row instead of 13 VALU
 //   V6  V5 + the wave_shr:1 fast path of V2 (the DS latency off the row-to-row chain)
+//   V8  V1 + the SGPR-mask capture: what the step kernel runs since round 5 (9 VALU per row)
+//   V7  V8 with the half-wave broadcast as two v_fmac_f32 with a scalar operand each, under the halves' exec masks (7 VALU + 3 SALU per row)
 //   V3  V2 with row_shr:1 + row_bcast:15 at the row-of-16 boundaries instead of wave_shr:1 (if wave_shr were not available)
 // V1, V2, V3 give bit-identical f and g (checked here); V0 differs from them by the rounding of the folded constants.
 //   hipcc --offload-arch=gfx950 -O3 -o pgs_chain pgs_chain.hip && ./pgs_chain
@@ -57,11 +59,20 @@ __global__ void __launch_bounds__(64) k(int nrows, int sweeps, const float* __re
 #pragma unroll
       for (int i = 0; i < kRows; i++) {
         if ((i & 3) == 0 && i >= nrows) break;
-        const float dl = fmaxf(__builtin_fmaf((V == 1 || V == 5) ? g : gt, k0, k1), nf);
+        const float dl = fmaxf(__builtin_fmaf((V == 1 || V == 5 || V == 7 || V == 8) ? g : gt, k0, k1), nf);
         if (V == 2) gt = __builtin_fmaf(dppmov<0x138>(dl, dl), Asub, g);                      // wave_shr:1
         if (V == 4) {      // the shift folded into the multiply-add: v_fmac_f32 with a DPP source (VOP2), one instruction on the chain
           gt = g;
           asm volatile("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(gt) : "v"(dl), "v"(Asub));
+        }
+        if (V == 7 || V == 8) {      // what the kernel does since round 5: capture the row's g under an SGPR literal mask (V8), and the broadcast as two
+                                     // multiply-adds with a scalar operand each under the halves' exec masks (V7)
+          asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %3\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(dcap) : "v"(dcap), "v"(dl), "n"(1u << i) : "vcc");
+          const float s0 = rdl(dl, i), s1 = rdl(dl, 32 + i);
+          if (V == 8) { const float b = h1 ? s1 : s0; g = __builtin_fmaf(A[i], b, g); }
+          else asm("s_nop 1\n\ts_mov_b32 exec_hi, 0\n\tv_fmac_f32_e32 %0, %2, %1\n\ts_not_b64 exec, exec\n\tv_fmac_f32_e32 %0, %3, %1\n\ts_mov_b64 exec, -1"
+                   : "+v"(g) : "v"(A[i]), "s"(s0), "s"(s1) : "scc");
+          continue;
         }
         if (V == 5 || V == 6) {      // broadcast through the LDS crossbar (ds_bpermute_b32: one DS instruction, no VALU slot, no SGPR), capture under an SGPR literal mask
           if (V == 6) gt = __builtin_fmaf(dppmov<0x138>(dl, dl), Asub, g);
@@ -105,7 +116,7 @@ int main() {
   unsigned s = 12345u;
   for (size_t i = 0; i < sizeof(hA) / 4; i++) { s = s * 1664525u + 1013904223u; hA[i] = ((s >> 8) & 0xffff) / 65536.0f * 0.06f - 0.03f; }
   (void)hipMemcpy(A, hA, sizeof(hA), hipMemcpyHostToDevice);
-  static float r[7][8 * 128];
+  static float r[9][8 * 128];
   for (int grid = 1024; grid <= 2048; grid += 1024)
     for (int nrows = 8; nrows <= 32; nrows += 8) {
       const double t0 = run<0>(grid, nrows, 300, A, out, ticks, r[0]), t1 = run<1>(grid, nrows, 300, A, out, ticks, r[1]);
@@ -114,6 +125,9 @@ int main() {
       const double t5 = run<5>(grid, nrows, 300, A, out, ticks, r[5]), t6 = run<6>(grid, nrows, 300, A, out, ticks, r[6]);
       printf("    V5 ds_bpermute broadcast + SGPR-mask capture %.1f | V6 = V5 + wave_shr:1 fast path %.1f  [V5 == V1: %s, V6 == V1: %s]\n", t5, t6,
              memcmp(r[1], r[5], sizeof(r[1])) ? "NO" : "yes", memcmp(r[1], r[6], sizeof(r[1])) ? "NO" : "yes");
+      const double t7 = run<7>(grid, nrows, 300, A, out, ticks, r[7]), t8 = run<8>(grid, nrows, 300, A, out, ticks, r[8]);
+      printf("    V8 = V1 + SGPR-mask capture (the round-5 kernel) %.1f | V7 = V8 with the broadcast as two exec-masked v_fmac with a scalar operand %.1f  [V8 == V1: %s, V7 == V1: %s]\n", t8, t7,
+             memcmp(r[1], r[8], sizeof(r[1])) ? "NO" : "yes", memcmp(r[1], r[7], sizeof(r[1])) ? "NO" : "yes");
       printf("waves/SIMD %d, %2d rows per env: ticks per row update  V0 %.1f | V1 folded constants %.1f | V2 + wave_shr:1 fast path %.1f | V3 row_shr + row_bcast %.1f | V4 v_fmac_dpp %.1f"
              "   [V2 == V1 bitwise: %s, V3 == V1: %s, V4 == V1: %s, max |V0 - V1| %.2e]\n", grid / 1024, nrows, t0, t1, t2, t3, t4,
              memcmp(r[1], r[2], sizeof(r[1])) ? "NO" : "yes", memcmp(r[1], r[3], sizeof(r[1])) ? "NO" : "yes", memcmp(r[1], r[4], sizeof(r[1])) ? "NO" : "yes",
