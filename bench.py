@@ -24,6 +24,8 @@ sys.path.insert(0, ROOT)
 
 B_FULL = 1092  # algorithmic HBM bytes per env-step, full step() (452 read + 640 written)
 B_DYN = 656    # dynamics-only (config 2)
+B_ROLLOUT = 1513  # one env-step inside the one-launch rollout: step() without the action read, + the observation read back from storage + the transition row
+MFMA_F32_PEAK_TF = 157.3  # dense f32 MFMA: 256 CUs x 256 flop/clk x 2.4 GHz (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
@@ -332,9 +334,22 @@ def main():
             graph.replay()
         torch.cuda.synchronize(dev)
         closed = E * 10 * per_graph / (time.perf_counter() - t1)
+        # ... and the policy kernel of that loop alone (k_mlp_fused, 66 -> 256 -> 256 -> 18 at E rows = 174 080 FLOP per row): its share of the
+        # dense f32 MFMA peak, driver-observed
+        o_fix = env.get_observations().clone()
+        for i in range(20):
+            net(o_fix)
+        e0.record(stream)
+        for i in range(200):
+            net(o_fix)
+        e1.record(stream)
+        e1.synchronize()
+        t_mlp = e0.elapsed_time(e1) / 200 * 1e-3
+        mlp = {"kernel": "k_mlp_fused", "shape": "66-256-256-18", "rows": E, "avg_us": t_mlp * 1e6, "tflops": 174080.0 * E / t_mlp / 1e12,
+               "frac_of_f32_mfma_peak": 174080.0 * E / t_mlp / 1e12 / MFMA_F32_PEAK_TF, "peak_tflops": MFMA_F32_PEAK_TF}
         # the collection loop of the PPO runner (reference train.py:54: act -> step -> process_env_step, 80 steps, the reference's 66-54-42-30-18|1
         # networks) as ONE launch with the policy inside the env's wave (nm_rollout): policy + step + transition record per env-step
-        roll = None
+        roll = roll_roof = None
         try:
             from nightmare_rl_amd.rl import ActorCritic, RolloutStorage
             from nightmare_rl_amd.rl.fused import FusedCollector, FusedUpdate
@@ -357,6 +372,28 @@ def main():
                     col.rollout(env, st, T, 0.99, cr, cl, fin, ep=(eidx, eacc))
                 torch.cuda.synchronize(dev)
                 roll = E * T * 5 / (time.perf_counter() - t1)
+                # its roofline: one launch = T steps of E envs; algorithmic bytes per env-step = step()'s 1092 minus the
+                # 72 B of actions it no longer reads, plus what the collection loop keeps: the previous observation read back from its storage
+                # row (264) and the transition row written (actions 72, log-prob 4, value 4, mean 72, sigma 72, reward 4, done 1) = 1513 B
+                e0.record(stream)
+                for i in range(5):
+                    col.rollout(env, st, T, 0.99, cr, cl, fin, ep=(eidx, eacc))
+                e1.record(stream)
+                e1.synchronize()
+                t_roll = e0.elapsed_time(e1) / 5 * 1e-3
+                rj = None
+                cr_ = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_rollout.json")))
+                if cr_:
+                    try:
+                        rj = json.load(open(cr_[-1]))
+                    except Exception:
+                        rj = None
+                roll_roof = {"bound": "hbm", "kernel": "k_env_rollout (+ k_rollout_tail)", "achieved": B_ROLLOUT * E * T / t_roll / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": B_ROLLOUT * E * T / t_roll / 1e9 / HBM_PEAK_GBS, "launch_avg_us": t_roll * 1e6, "us_per_step": t_roll * 1e6 / T, "steps_per_launch": T,
+                             "algorithmic_bytes_per_env_step": B_ROLLOUT,
+                             "traffic": rj and rj.get("hbm_bytes_per_launch") and rj["hbm_bytes_per_launch"] * (E / float(rj.get("envs", 4096))) * (T / float(rj.get("steps", 80))),
+                             "l2_to_cu_read_GBps_under_profiler": rj and rj.get("l2_read_GBps"),
+                             "traffic_source": cr_ and rj and os.path.relpath(cr_[-1], ROOT) + " (rocprofv3 --pmc passes over scripts/pmcrollout.py; not measured in this run)"}
         except Exception as exc:       # a secondary figure: never fails the headline
             roll = f"failed: {type(exc).__name__}: {exc}"
         # BASELINE config 5 on this one GPU: the reference's full PPO loop (train.py:54 -> OnPolicyRunner.learn: 80 steps per env, 5 epochs x 4
@@ -413,13 +450,50 @@ def main():
             "contact_regime": regime,
             "physics_only_env_steps_per_s": phys,
             "closed_loop_mlp_2x256_env_steps_per_s": closed,
-            "policy_rollout_one_launch_env_steps_per_s": roll, "ppo_end_to_end_env_steps_per_s": ppo_e2e,
+            "mlp_2x256": mlp,
+            "policy_rollout_one_launch_env_steps_per_s": roll, "rollout_roofline": roll_roof, "ppo_end_to_end_env_steps_per_s": ppo_e2e,
             "fp64_verification_kernel_env_steps_per_s": f64,
             "counters": env.counters(),
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(E)
     if world > 1:
+        # BASELINE config 5 at N > 1: the full PPO loop, `E` envs per rank, data-parallel update (one RCCL all-reduce of
+        # gradient | KL per mini-batch, inside the update's graph), whole-job env-steps/s. Runs LAST and under a deadline: the headline
+        # numbers above are complete, and if this leg should hang on some node (it is the one part of this file that only a multi-GPU
+        # node ever runs over RCCL) every rank still leaves with status 0 after rank 0 has printed the line, the leg marked "timed out".
+        import threading
+
+        def bail():
+            if rank == 0:
+                out["ppo_end_to_end_env_steps_per_s"] = "timed out (multi-rank PPO leg exceeded its deadline)"
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dist.barrier()
+        watchdog = threading.Timer(float(os.environ.get("NM_BENCH_PPO_DEADLINE_S", "240")), bail)
+        watchdog.daemon = True
+        watchdog.start()
+        ppo_e2e = None
+        try:
+            from nightmare_rl_amd.envs.helpers import class_to_dict
+            from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3ConfigPPO
+            from nightmare_rl_amd.rl import OnPolicyRunner
+            torch.manual_seed(rank)
+            cfgp = NightmareV3Config()
+            cfgp.env.num_envs = E
+            envp = NightmareV3Env(cfgp, device=dev, seed=0, env_id_offset=rank * E)
+            runner = OnPolicyRunner(envp, class_to_dict(NightmareV3ConfigPPO()), log_dir=None, device=str(dev))
+            runner.learn(16, init_at_random_ep_len=True)
+            h = runner.history[6:]
+            ppo_e2e = {"value": sum(r["fps"] for r in h) / len(h), "envs_total": world * E, "update": "data-parallel, all-reduce of gradient | KL per mini-batch",
+                       "update_graph": getattr(runner.alg, "_upd_graph", None) not in (None, "failed"), "logging": runner.logging_mode, "rollout": runner.rollout_mode}
+            envp.close()
+        except Exception as exc:
+            ppo_e2e = f"failed: {type(exc).__name__}: {exc}"
+        watchdog.cancel()
+        if rank == 0:
+            out["ppo_end_to_end_env_steps_per_s"] = ppo_e2e
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -236,6 +236,10 @@ int nm_ppo_record_act(nm_ppo* h, const float* rew_dev, const int64_t* done_dev, 
 /* gradient of the last mini-batch in flat order followed by the mini-batch's mean KL to the behaviour policy, [num_params + 1] floats:
  * direction 0 copies them to grad_dev, 1 replaces them by grad_dev */
 int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream);
+/* The same vector in a buffer the caller owns ([num_params + 1] floats on the device): phase 1 writes gradient | KL there, phase 2 reads it
+ * from there, and a data-parallel update all-reduces it IN PLACE between the two - one collective per mini-batch and nothing else (the 60 KB
+ * gradient all-reduce of SURVEY 8(e); rsl_rl v1.0.2 itself is single-process, caller reference train.py:54). NULL = the handle's own buffer. */
+int nm_ppo_set_grad_buffer(nm_ppo* h, float* grad_kl_dev);
 /* HOST out[8]: lr, Adam steps, last KL, sum of value losses, sum of surrogate losses, mini-batches, clip coefficient, grad norm;
  * reset_sums != 0 clears the two loss sums and the count afterwards. Synchronises the stream. */
 int nm_ppo_get_state(nm_ppo* h, float* out8_host, int32_t reset_sums, void* stream);

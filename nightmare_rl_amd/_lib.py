@@ -10,7 +10,7 @@ DTYPE_F32, DTYPE_F64 = 0, 1
 
 EXPORTS = ["nm_default_config", "nm_reward_name", "nm_last_error", "nm_create", "nm_destroy", "nm_num_envs", "nm_dtype", "nm_reset",
            "nm_step", "nm_step_physics", "nm_get_state", "nm_set_state", "nm_get_buffers", "nm_set_buffers",
-           "nm_set_command_uniforms", "nm_get_feet_state", "nm_set_feet_state", "nm_get_counters", "nm_set_debug_buffer", "nm_set_return_accumulator", "nm_invalidate_time_outs", "nm_rollout", "nm_rollout_act", "nm_rollout_supported", "nm_policy_create", "nm_policy_destroy", "nm_policy_load", "nm_policy_forward", "nm_profile", "nm_gae", "nm_gae_advantages", "nm_ppo_sample", "nm_ppo_record", "nm_ppo_create", "nm_ppo_destroy", "nm_ppo_num_params", "nm_ppo_sync_params", "nm_ppo_minibatch", "nm_ppo_minibatch_rows", "nm_ppo_set_storage_rows", "nm_ppo_step_is_fused", "nm_ppo_debug_break_barrier", "nm_ppo_permutation", "nm_ppo_copy_grad", "nm_ppo_get_state", "nm_ppo_snapshot_state", "nm_ppo_has_fast_path", "nm_ppo_act", "nm_ppo_record_act",
+           "nm_set_command_uniforms", "nm_get_feet_state", "nm_set_feet_state", "nm_get_counters", "nm_set_debug_buffer", "nm_set_return_accumulator", "nm_invalidate_time_outs", "nm_rollout", "nm_rollout_act", "nm_rollout_supported", "nm_policy_create", "nm_policy_destroy", "nm_policy_load", "nm_policy_forward", "nm_profile", "nm_gae", "nm_gae_advantages", "nm_ppo_sample", "nm_ppo_record", "nm_ppo_create", "nm_ppo_destroy", "nm_ppo_num_params", "nm_ppo_sync_params", "nm_ppo_minibatch", "nm_ppo_minibatch_rows", "nm_ppo_set_storage_rows", "nm_ppo_step_is_fused", "nm_ppo_debug_break_barrier", "nm_ppo_permutation", "nm_ppo_copy_grad", "nm_ppo_set_grad_buffer", "nm_ppo_get_state", "nm_ppo_snapshot_state", "nm_ppo_has_fast_path", "nm_ppo_act", "nm_ppo_record_act",
            "nm_set_observation_noise", "nm_set_noise_uniforms", "nm_set_state_record", "nm_get_state_record",
            "nm_nik_create", "nm_nik_destroy", "nm_nik_reset", "nm_nik_set_gait", "nm_nik_update", "nm_nik_get_state"]
 
@@ -130,6 +130,7 @@ def _bind(L, full):
                                                     C.c_float, C.c_float, C.c_float, C.c_int32, C.c_float, vp]
     L.nm_ppo_permutation.argtypes = [vp, C.c_int32, C.c_uint64, C.c_uint64, vp]
     L.nm_ppo_copy_grad.argtypes = [vp, vp, C.c_int32, vp]
+    L.nm_ppo_set_grad_buffer.argtypes = [vp, vp]
     L.nm_ppo_has_fast_path.argtypes = [vp]
     L.nm_ppo_act.argtypes = [vp, vp, vp, C.c_int32, C.c_uint64, vp, C.c_int32, vp, vp, vp, vp, vp, vp, vp]
     L.nm_ppo_record_act.argtypes = [vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp, vp, vp, C.c_int32, vp,

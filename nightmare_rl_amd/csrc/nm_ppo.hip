@@ -1261,6 +1261,7 @@ struct nm_ppo {
   float* Wm = nullptr;         // merged matrices, all layers
   f32x4 *pf = nullptr, *pb = nullptr;
   float *partial = nullptr, *grad = nullptr, *state = nullptr;
+  float* grad_ext = nullptr;   // caller-owned gradient | KL buffer (nm_ppo_set_grad_buffer): what a data-parallel update all-reduces in place
   int *pfi = nullptr, *pbi = nullptr;       // per flat parameter: its float position in pf / pb (k_ppo_step writes the packings itself)
   float* n2part = nullptr;
   unsigned* bar = nullptr;
@@ -1455,6 +1456,15 @@ extern "C" int nm_ppo_create(const int32_t* actor_dims, const int32_t* critic_di
   return 0;
 }
 extern "C" int32_t nm_ppo_num_params(const nm_ppo* h) { return h ? h->nparam : 0; }
+static inline float* ppo_grad(nm_ppo* h) { return h->grad_ext ? h->grad_ext : h->grad; }
+// The gradient | mean-KL vector of a mini-batch ([num_params + 1] floats, device) in a buffer the CALLER owns: phase 1 of nm_ppo_minibatch
+// writes it there, phase 2 reads it from there - a data-parallel update all-reduces that buffer in place (one collective per mini-batch,
+// no copies around it: nm_ppo_copy_grad is then not needed). NULL returns to the handle's own buffer.
+extern "C" int nm_ppo_set_grad_buffer(nm_ppo* h, float* grad_kl_dev) {
+  if (!h) return nm_policy_set_error("nm_ppo_set_grad_buffer: bad argument");
+  h->grad_ext = grad_kl_dev;
+  return 0;
+}
 
 static int ppo_pack(nm_ppo* h, hipStream_t s) {
   int most = 0;
@@ -1522,12 +1532,12 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     if (h->fast) hipLaunchKernelGGL(k_ppo_fwdbwd_split<RefShape>, dim3(2 * grid), dim3(64 * kSplitWaves), 0, s, h->net, bt, h->partial);      // two blocks (actor, critic) per partial row
     else hipLaunchKernelGGL(k_ppo_fwdbwd, dim3(grid), dim3(kThreads), 0, s, h->net, bt, h->partial);
     if (phase == 1 || !h->fused_step)
-      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nrows, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, h->grad, h->fast ? 1 : 0);
+      hipLaunchKernelGGL(k_ppo_reduce, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, h->partial, h->nrows, stride, h->map, h->nparam, h->net.gtotal, flat_dev, entropy_coef, 1.0f / (float)B, ppo_grad(h), h->fast ? 1 : 0);
   }
   if ((phase == 0 || phase == 2) && h->fused_step) {     // reduce (phase 0) + scalars + Adam + both packings: one launch
     StepArgs a;
     a.partial = h->partial; a.nwg = h->nrows; a.stride = stride; a.gtotal = h->net.gtotal; a.map = h->map; a.n = h->nparam;
-    a.flat = flat_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev; a.grad = h->grad; a.state = h->state; a.Wm = h->Wm; a.n2part = h->n2part;
+    a.flat = flat_dev; a.m = exp_avg_dev; a.v = exp_avg_sq_dev; a.grad = ppo_grad(h); a.state = h->state; a.Wm = h->Wm; a.n2part = h->n2part;
     a.pf = reinterpret_cast<float*>(h->pf); a.pb = reinterpret_cast<float*>(h->pb); a.pfi = h->pfi; a.pbi = h->pbi; a.bar = h->bar;
     a.sf = h->sf; a.sb = h->sb; a.sfi = h->sfi; a.sbi = h->sbi;
     a.compact = h->fast ? 1 : 0;
@@ -1535,9 +1545,9 @@ extern "C" int nm_ppo_minibatch_rows(nm_ppo* h, float* flat_dev, float* exp_avg_
     a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.adaptive = adaptive; a.kl_from_grad = phase == 2 ? 1 : 0; a.do_reduce = phase == 0 ? 1 : 0;
     hipLaunchKernelGGL(k_ppo_step, dim3(nbr), dim3(kRedParams * kRedWaves), 0, s, a);
   } else if (phase == 0 || phase == 2) {     // 2: the step, after the caller has all-reduced gradient | KL; the KL is then read from there
-    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nrows, stride, h->net.gtotal, h->grad, h->nparam, 1.0f / (float)B, desired_kl,
+    hipLaunchKernelGGL(k_ppo_scalars, dim3(1), dim3(1024), 0, s, h->partial, h->nrows, stride, h->net.gtotal, ppo_grad(h), h->nparam, 1.0f / (float)B, desired_kl,
                        adaptive, max_grad_norm, kl_override, phase == 2 ? 1 : 0, h->state);
-    hipLaunchKernelGGL(k_ppo_adam, dim3(nb), dim3(256), 0, s, flat_dev, exp_avg_dev, exp_avg_sq_dev, h->grad, h->nparam, h->state, beta1, beta2, eps, h->map, h->Wm);
+    hipLaunchKernelGGL(k_ppo_adam, dim3(nb), dim3(256), 0, s, flat_dev, exp_avg_dev, exp_avg_sq_dev, ppo_grad(h), h->nparam, h->state, beta1, beta2, eps, h->map, h->Wm);
     if (ppo_pack(h, s)) return 1;
   }
   if (hipGetLastError() != hipSuccess) return nm_policy_set_error("nm_ppo_minibatch: launch failed");
@@ -1580,7 +1590,7 @@ extern "C" int nm_ppo_record_act(nm_ppo* h, const float* rew, const int64_t* don
 extern "C" int nm_ppo_copy_grad(nm_ppo* h, float* grad_dev, int32_t direction, void* stream) {
   if (!h || !grad_dev) return nm_policy_set_error("nm_ppo_copy_grad: bad argument");
   PPO_CHK(hipSetDevice(h->device));
-  PPO_CHK(hipMemcpyAsync(direction ? h->grad : grad_dev, direction ? grad_dev : h->grad, ((size_t)h->nparam + 1) * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  PPO_CHK(hipMemcpyAsync(direction ? ppo_grad(h) : grad_dev, direction ? grad_dev : ppo_grad(h), ((size_t)h->nparam + 1) * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
   return 0;
 }
 // out_dev[i] = image of i under a random permutation of 0..n-1 keyed by (seed, counter): the mini-batch order of one PPO.update

@@ -287,16 +287,20 @@ class FusedUpdate:
         return out
 
     def minibatch_data_parallel(self, *batch, hp, world, rows=None):
-        """One mini-batch of a data-parallel update: local gradient, ONE all-reduce of gradient | KL (RCCL when the process group is
-        nccl; every rank then applies the identical step), the step."""
+        """One mini-batch of a data-parallel update: local gradient (phase 1 writes gradient | KL straight into a buffer this object
+        owns), ONE all-reduce of that buffer in place - averaged by RCCL itself when the process group is nccl, summed and divided on
+        other backends -, then the step (phase 2 reads the buffer; every rank applies the identical step). Four launches per mini-batch
+        (forward / backward, reduce, all-reduce, step), nothing read by the host: the whole update can be captured into a graph."""
         import torch.distributed as dist
-        self.minibatch(*batch, hp, phase=1, rows=rows)
         if getattr(self, "_gbuf", None) is None:
-            self._gbuf = torch.empty(self.flat.numel() + 1, device=self.device)
-        self.grad_and_kl(self._gbuf)
-        dist.all_reduce(self._gbuf)
-        self._gbuf.div_(world)
-        self.set_grad_and_kl(self._gbuf)
+            self._gbuf = torch.zeros(self.flat.numel() + 1, device=self.device)
+            _lib.check(self._L.nm_ppo_set_grad_buffer(self._h, C.c_void_p(self._gbuf.data_ptr())))
+        self.minibatch(*batch, hp, phase=1, rows=rows)
+        if dist.get_backend() == "nccl":
+            dist.all_reduce(self._gbuf, op=dist.ReduceOp.AVG)
+        else:
+            dist.all_reduce(self._gbuf)
+            self._gbuf.div_(world)
         self.minibatch(*batch, hp, phase=2, rows=rows)
 
     def read_state(self, reset_sums=True):

@@ -2,6 +2,8 @@
 (rsl_rl v1.0.2 `algorithms/ppo.py` semantics; reference hyper-parameters envs/nightmare_v3_config.py:111-128).
 With torch.distributed initialised, gradients are averaged across ranks with one flat all-reduce per mini-batch and
 the KL used for the learning-rate schedule is the global mean, so every rank takes identical steps."""
+import os
+
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -178,7 +180,10 @@ class PPO:
             # moment vectors; learning rate, KL and Adam's step count live on the device): from the third update on, the 2 x epochs x
             # mini-batches launches are ONE HIP graph replay. The permutation above is redrawn every update outside the graph.
             key = (tuple(t.data_ptr() for t in flat), self._perm.data_ptr(), mb, tuple(sorted(hp.items())))
-            if self.update_graph and _world() == 1 and torch.device(self.device).type == "cuda":
+            # With several ranks the graph also holds the all-reduce of every mini-batch (RCCL collectives are capturable; on other
+            # backends - the shared-card gloo rehearsal - the update stays on per-launch issue).
+            dp_graph = _world() == 1 or (dist.get_backend() == "nccl" and os.environ.get("NM_DP_UPDATE_GRAPH", "1") != "0")
+            if self.update_graph and dp_graph and torch.device(self.device).type == "cuda":
                 if getattr(self, "_upd_graph", None) is not None and self._upd_graph[0] == key:
                     self._upd_graph[1].replay()
                     fu.step_count += self.num_learning_epochs * self.num_mini_batches

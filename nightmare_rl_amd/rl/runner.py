@@ -143,12 +143,14 @@ class OnPolicyRunner:
             and not getattr(env, "add_noise", False) and not getattr(getattr(env.cfg, "viewer", None), "record_states", False)
         graph = None
         ev0, ev1 = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if on_gpu else (None, None)
-        # Pipelined logging (one GPU, fused update): rsl_rl's runner reads the iteration's statistics from the device after every update
+        # Pipelined logging (fused update): rsl_rl's runner reads the iteration's statistics from the device after every update
         # (OnPolicyRunner.log; caller reference train.py:54) - a handful of host synchronisations during which the GPU idles (measured:
         # 0.2 ms of a 7.4 ms iteration, 0.5 ms under the profiler). Here the statistics of iteration i are copied, stream-ordered, into a pinned host buffer and READ
         # after iteration i + 1 has been enqueued; iterations that save a checkpoint, and the last one, are drained at once, so a
         # checkpoint still holds exactly the state after its iteration. cfg pipeline_logging=False restores the synchronous loop.
-        pipe = on_gpu and _world() == 1 and getattr(alg, "fused_update", None) is not None and bool(self.cfg.get("pipeline_logging", True))
+        # With several ranks the iteration's statistics that span ranks (finished episodes, mean step reward) are all-reduced ON THE DEVICE
+        # inside the snapshot - one small collective per iteration, enqueued like everything else - and read one iteration later as well.
+        pipe = on_gpu and getattr(alg, "fused_update", None) is not None and bool(self.cfg.get("pipeline_logging", True))
         self.logging_mode = "pipelined (read one iteration later)" if pipe else "synchronous"
         kSnap = 9 + 3 + 1 + 1                     # PPO state | finished episodes | mean step reward | mean action std | extras['episode'] sums follow
         slots = []                                # two sets of (pinned host buffer, events) used alternately
@@ -252,6 +254,9 @@ class OnPolicyRunner:
                         keys = list(state["ep_keys"]) if (ep_stats is not None and state["ep_keys"]) else []
                         snap_dev[9:12].copy_(fin)
                         snap_dev[12].copy_(step_rew)
+                        if _world() > 1:
+                            dist.all_reduce(snap_dev[9:13])       # sums over the ranks, still on the device; the mean step reward is divided below
+                            snap_dev[12].div_(_world())
                         snap_dev[13].copy_(alg.actor_critic.std.detach().mean())
                         if keys:
                             snap_dev[kSnap:kSnap + len(keys)].copy_(ep_stats)

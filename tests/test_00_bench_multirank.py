@@ -75,6 +75,9 @@ def test_two_rank_bench_times_a_collective():
     assert out["collectives_timed"] >= 1
     assert out["config"]["envs_per_gpu"] == 1024
     assert abs(out["value"] - 2 * 1024 * 20 / (out["ms_per_step"] * 20 / 1e3)) < 1e-6 * out["value"]   # whole-job aggregate
+    ppo = out["ppo_end_to_end_env_steps_per_s"]             # BASELINE config 5 at N > 1: the data-parallel PPO loop, whole-job env-steps/s
+    assert isinstance(ppo, dict) and ppo["value"] > 0 and ppo["envs_total"] == 2 * 1024, ppo
+    assert ppo["logging"].startswith("pipelined") and ppo["rollout"].startswith("one launch"), ppo
     assert "cpu_baseline" not in out                                                                    # rank 0 at N=1 only
 
 
