@@ -13,6 +13,12 @@ from .fused import FusedCollector, FusedUpdate
 from .storage import RolloutStorage
 
 
+def _dp():
+    """Is the update data-parallel? Several ranks - or ONE rank with NM_FORCE_DATA_PARALLEL=1 and an initialised process group: the measurement
+    switch that sends a single GPU down the multi-rank code path (all-reduces over RCCL included) so that its kernel trace can be looked at."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or os.environ.get("NM_FORCE_DATA_PARALLEL") == "1")
+
+
 def _world():
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -171,7 +177,7 @@ class PPO:
                 for _ in range(self.num_learning_epochs):
                     for i in range(self.num_mini_batches):
                         rows = self._perm[i * mb:(i + 1) * mb]
-                        if _world() > 1:
+                        if _dp():
                             fu.minibatch_data_parallel(*flat, hp=hp, world=_world(), rows=rows)
                         else:
                             fu.minibatch(*flat, hp, rows=rows)
@@ -182,7 +188,7 @@ class PPO:
             key = (tuple(t.data_ptr() for t in flat), self._perm.data_ptr(), mb, tuple(sorted(hp.items())))
             # With several ranks the graph also holds the all-reduce of every mini-batch (RCCL collectives are capturable; on other
             # backends - the shared-card gloo rehearsal - the update stays on per-launch issue).
-            dp_graph = _world() == 1 or (dist.get_backend() == "nccl" and os.environ.get("NM_DP_UPDATE_GRAPH", "1") != "0")
+            dp_graph = not _dp() or (dist.get_backend() == "nccl" and os.environ.get("NM_DP_UPDATE_GRAPH", "1") != "0")
             if self.update_graph and dp_graph and torch.device(self.device).type == "cuda":
                 if getattr(self, "_upd_graph", None) is not None and self._upd_graph[0] == key:
                     self._upd_graph[1].replay()
@@ -211,7 +217,7 @@ class PPO:
             for (obs, _cobs, actions, target_values, advantages, returns, old_logp, old_mu, old_sigma, _hid, _mask) in \
                     self.storage.mini_batch_generator(self.num_mini_batches, self.num_learning_epochs):
                 batch = (obs, actions, target_values.reshape(-1), advantages.reshape(-1), returns.reshape(-1), old_logp.reshape(-1), old_mu, old_sigma)
-                if _world() > 1:
+                if _dp():
                     fu.minibatch_data_parallel(*batch, hp=hp, world=_world())
                 else:
                     fu.minibatch(*batch, hp)

@@ -14,7 +14,7 @@ import torch
 import torch.distributed as dist
 
 from .actor_critic import ActorCritic
-from .ppo import PPO
+from .ppo import PPO, _dp
 
 _CLASSES = {"ActorCritic": ActorCritic, "PPO": PPO}
 
@@ -254,7 +254,7 @@ class OnPolicyRunner:
                         keys = list(state["ep_keys"]) if (ep_stats is not None and state["ep_keys"]) else []
                         snap_dev[9:12].copy_(fin)
                         snap_dev[12].copy_(step_rew)
-                        if _world() > 1:
+                        if _world() > 1 or _dp():
                             dist.all_reduce(snap_dev[9:13])       # sums over the ranks, still on the device; the mean step reward is divided below
                             snap_dev[12].div_(_world())
                         snap_dev[13].copy_(alg.actor_critic.std.detach().mean())

@@ -41,9 +41,12 @@ def main():
     if backend != "nccl":
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    if world > 1 or os.environ.get("NM_FORCE_DATA_PARALLEL") == "1":      # (the switch: one rank down the multi-rank path, for a kernel trace)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29571")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
