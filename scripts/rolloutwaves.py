@@ -42,25 +42,15 @@ torch.cuda.synchronize()
 env.set_debug_buffer(None)
 clk = dbg.view(torch.int64).reshape(-1)[: N].cpu().numpy().astype(np.int64).reshape(-1, 2)   # [waves][start, end], waves = N / 2
 clk = clk[: N // 2]
-# s_memtime is a per-XCD counter: the eight XCDs' clocks have unrelated bases (round 4's report subtracted across them and printed a span of
-# 3e11 ticks). Waves are grouped by clock domain - start values more than 1e9 ticks apart cannot belong to one 4 ms launch - and every
-# difference below is taken inside a group.
-order = np.argsort(clk[:, 0])
-grp = np.zeros(len(clk), dtype=np.int64)
-grp[order] = np.concatenate([[0], np.cumsum(np.diff(clk[order, 0]) > 1_000_000_000)])
-ngrp = int(grp.max()) + 1
+# Only differences INSIDE a wave are taken: s_memtime has no common base across the chip (round 4's report subtracted start clocks of
+# different waves and printed a span of 3e11 ticks; grouping the waves by XCD still leaves start values tens of millions of ticks apart
+# inside a group - more than five launches' worth). What the per-wave times do give: the tick rate (the slowest wave spans all but the
+# launch ramp of the kernel, whose duration the event pair measures) and how evenly the waves finish.
 life = (clk[:, 1] - clk[:, 0]).astype(np.float64)
-spans, skews = [], []
-for gidx in range(ngrp):
-    c = clk[grp == gidx]
-    spans.append(float(c[:, 1].max() - c[:, 0].min()))
-    skews.append(float(c[:, 0].max() - c[:, 0].min()))
-span = max(spans)
 ms = e0.elapsed_time(e1)
-tick_ns = ms * 1e6 / span
-print(f"{N} envs x {T} steps: launches {ms:.3f} ms; {ngrp} clock domains (XCDs) of {np.bincount(grp).tolist()} waves; rollout kernel span per domain "
-      f"{min(spans):.0f} .. {span:.0f} ticks ({tick_ns:.3f} ns per tick of the longest, incl. the tail launches and the launch latency)")
+tick_ns = ms * 1e6 / life.max()
+print(f"{N} envs x {T} steps: launches {ms:.3f} ms (event pair around nm_rollout: k_env_rollout + k_rollout_tail); slowest wave {life.max():.0f} ticks -> "
+      f">= {1.0 / tick_ns:.2f} ticks per ns")
 print(f"wave total time (ticks): mean {life.mean():.0f}  p50 {np.median(life):.0f}  p90 {np.percentile(life, 90):.0f}  p99 {np.percentile(life, 99):.0f}  max {life.max():.0f}"
       f"   max / mean {life.max() / life.mean():.3f}   per step: mean {life.mean() / T:.0f}  max {life.max() / T:.0f}")
-print(f"start skew inside a domain: the last wave starts {max(skews):.0f} ticks after the first (worst domain); "
-      f"sum of wave times / (waves x span of their domain) = {sum(life[grp == gidx].sum() / ((grp == gidx).sum() * spans[gidx]) for gidx in range(ngrp)) / ngrp:.3f}")
+print(f"mean wave time / slowest wave = {life.mean() / life.max():.3f}: the share of the launch the average wave slot is occupied (no wave waits for another inside the launch)")
