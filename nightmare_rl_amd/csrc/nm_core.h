@@ -2035,6 +2035,7 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
       A[4 * cc + 2] = A[4 * cc + 2] - A[4 * cc + 3];
     });
     VB run = VB(true);
+    const bool anysmall = wany(small & act);
     for (int iter = 0; iter < (nosweep ? 0 : M.noslip_iters); iter++) {
       vr improvement = vr(real(0));
       if (iter == 0) improvement = hsum32(sel(act, real(0.5) * f * f * Rr, vr(real(0))));
@@ -2043,16 +2044,25 @@ template <class real> NM_FN void stage_constraint2(ShW<real, 2>& w, const Model<
       lo = sel(run, lo, vr(real(0))); hi = sel(run, hi, vr(real(0)));
       vr dcap = vr(real(0)), dgcap = vr(real(0));
       uint64_t pairm = mask_shl(0x0000000300000003ull, 0);
-      sfor_pairs<kMaxRow2 / 2>(nmax, [&](auto pT) {
-        constexpr int p = decltype(pT)::value;
-        const vr dg = g - shfl_xor1(g);
-        vr d = noslip_pair_delta(dg, invK1, lo, hi);
-        d = sel(noslip_pair_bad<real>(noslip_pair_cost(d, hK1, dg)), vr(real(0)), d);
-        g = fma_half_lane<2 * p>(A[2 * p], d, g, h1);
-        dcap = sel_mask(pairm, d, dcap);
-        dgcap = sel_mask(pairm, dg, dgcap);
-        pairm = mask_shl(pairm, 2);
-      });
+      // mj_solNoSlip's revert test (cost change > 1e-10) can only fire on a DEGENERATE pair: with K1 > 0 the step is d = clamp(-dg / K1) to
+      // [-f, fp] (-f <= 0 <= fp), so d and 0.5 K1 d + dg have opposite signs or one of them is zero in every case of the clamp - unclamped the
+      // second factor is ~ dg / 2, clamped at -f (then dg > 0) it lies in [dg / 2, dg], at fp (dg < 0) in [dg, dg / 2] - and the change
+      // d (0.5 K1 d + dg) <= 0 in floating point as well (the signs of the factors are exact, the magnitudes far from cancelling). So the
+      // test (fma, mul, compare, select: 4 of a pair's 16 VALU instructions) runs only in sweeps of a wave that HAS a degenerate pair -
+      // one uniform branch per sweep; same results either way.
+      auto pair_sweep = [&](auto checkT) {
+        sfor_pairs<kMaxRow2 / 2>(nmax, [&](auto pT) {
+          constexpr int p = decltype(pT)::value;
+          const vr dg = g - shfl_xor1(g);
+          vr d = noslip_pair_delta(dg, invK1, lo, hi);
+          if constexpr (decltype(checkT)::value) d = sel(noslip_pair_bad<real>(noslip_pair_cost(d, hK1, dg)), vr(real(0)), d);
+          g = fma_half_lane<2 * p>(A[2 * p], d, g, h1);
+          dcap = sel_mask(pairm, d, dcap);
+          dgcap = sel_mask(pairm, dg, dgcap);
+          pairm = mask_shl(pairm, 2);
+        });
+      };
+      if (anysmall) pair_sweep(std::true_type{}); else pair_sweep(std::false_type{});
       f = f + dcap;
       improvement = improvement - hsum32(sel(even, noslip_pair_cost(dcap, hK1, dgcap), vr(real(0))));
       itn = itn + sel(run, V<int>(1), V<int>(0));
