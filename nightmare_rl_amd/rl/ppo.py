@@ -200,7 +200,10 @@ class PPO:
                         # under inference_mode like the runner's rollout capture: torch keeps per-generator capture tensors, and whichever
                         # capture of the process comes first decides whether they are inference tensors - in-place updates of those are
                         # allowed in here in both cases, outside only in one
-                        with torch.inference_mode(), torch.cuda.graph(g):
+                        # with a process group alive, its watchdog thread may touch the runtime while this thread captures: thread-local
+                        # capture mode keeps such a call from invalidating the capture (the collectives themselves are issued by this thread)
+                        mode = "thread_local" if _dp() else "global"
+                        with torch.inference_mode(), torch.cuda.graph(g, capture_error_mode=mode):
                             epochs()
                         self._upd_graph = (key, g)
                         g.replay()             # the capture executed nothing

@@ -100,7 +100,7 @@ def main():
         fa.minibatch_data_parallel(*flat, hp=hp, world=1, rows=perm[:mb])
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.inference_mode(), torch.cuda.graph(g):
+        with torch.inference_mode(), torch.cuda.graph(g, capture_error_mode="thread_local"):     # as rl/ppo.py captures the data-parallel update
             update(fb)
         for rep in range(2):
             update(fa)
