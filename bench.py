@@ -466,7 +466,8 @@ def main():
 
         def bail():
             if rank == 0:
-                out["ppo_end_to_end_env_steps_per_s"] = "timed out (multi-rank PPO leg exceeded its deadline)"
+                if out.get("ppo_end_to_end_env_steps_per_s") is None:
+                    out["ppo_end_to_end_env_steps_per_s"] = "timed out (multi-rank PPO leg exceeded its deadline)"
                 print(json.dumps(out), flush=True)
             os._exit(0)
 
@@ -491,11 +492,11 @@ def main():
             envp.close()
         except Exception as exc:
             ppo_e2e = f"failed: {type(exc).__name__}: {exc}"
-        watchdog.cancel()
         if rank == 0:
             out["ppo_end_to_end_env_steps_per_s"] = ppo_e2e
-        dist.barrier()
+        dist.barrier()                      # still under the deadline: a communicator left unusable by a failed leg must not hang the line either
         dist.destroy_process_group()
+        watchdog.cancel()
     if rank == 0:
         print(json.dumps(out))
 
