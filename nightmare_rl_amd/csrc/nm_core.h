@@ -1329,12 +1329,6 @@ template <int NP, int P = 0, class F> NM_FN void sfor_pairs(int ncon, F&& f) {
     }
   }
 }
-// compile-time lane masks of the row layouts (sel_lanes): row i of a one-env wave is lane i; of the two-env pass lanes i and 32 + i;
-// pair p = the two lanes 2p, 2p + 1 (in both halves)
-template <int I> struct Row1Mask { static constexpr uint32_t lo = I < 32 ? (1u << (I & 31)) : 0u, hi = I >= 32 ? (1u << (I & 31)) : 0u; };
-template <int P> struct Pair1Mask { static constexpr uint32_t lo = 2 * P < 32 ? (3u << ((2 * P) & 31)) : 0u, hi = 2 * P >= 32 ? (3u << ((2 * P) & 31)) : 0u; };
-template <int I> struct Row2Mask { static constexpr uint32_t lo = 1u << I, hi = 1u << I; };
-template <int P> struct Pair2Mask { static constexpr uint32_t lo = 3u << (2 * P), hi = 3u << (2 * P); };
 // ---- The two update rules of the constraint solver, stated ONCE. The three row layouts below (row per lane on 64 lanes, two envs on
 // half-waves, matrix-free rows in three slots per lane) differ in how a row's delta reaches the other rows' residuals - a v_readlane
 // broadcast into a register-resident A row, two of them under the halves' masks, a block-factor solve through LDS - not in these

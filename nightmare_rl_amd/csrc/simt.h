@@ -82,9 +82,6 @@ NM_FN double vrcp(double x) { return 1.0 / x; }
 // row layout: the contraction is not left to the compiler's mood)
 NM_FN float vfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 NM_FN double vfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
-// a in the lanes of the compile-time mask (LO: lanes 0..31, HI: lanes 32..63), b elsewhere. The mask is a literal in two scalar moves
-// (SALU, not a VALU slot) instead of a v_cmp against the lane id per use: the solver sweeps keep one value per row at that row's own
-// step, i.e. one of these per row and sweep - and 64 loop-invariant compare masks would not fit the scalar register file.
 // a in the lanes of the wave-uniform 64-bit lane mask m (an SGPR pair), b elsewhere: ONE v_cndmask. The sweeps walk their rows in lane
 // order, so the mask of row i + 1 is the mask of row i shifted by one (s_lshl_b64): two instructions per kept value instead of three.
 NM_FN float sel_mask(uint64_t m, float a, float b) {
@@ -101,17 +98,6 @@ NM_FN double sel_mask(uint64_t m, double a, double b) {
 // m << k as a value the optimiser cannot fold (the rows are unrolled, so it would otherwise turn the walking mask into one 64-bit literal
 // per row and keep them all in scalar registers: 334 SGPR spills)
 NM_FN uint64_t mask_shl(uint64_t m, int k) { m <<= k; asm("" : "+s"(m)); return m; }
-template <uint32_t LO, uint32_t HI> NM_FN float sel_lanes(float a, float b) {
-  float r;
-  asm("s_mov_b32 vcc_lo, %3\n\ts_mov_b32 vcc_hi, %4\n\tv_cndmask_b32_e32 %0, %1, %2, vcc" : "=v"(r) : "v"(b), "v"(a), "n"(LO), "n"(HI) : "vcc");
-  return r;
-}
-template <uint32_t LO, uint32_t HI> NM_FN double sel_lanes(double a, double b) {
-  int rl, rh;
-  asm("s_mov_b32 vcc_lo, %5\n\ts_mov_b32 vcc_hi, %6\n\tv_cndmask_b32_e32 %0, %2, %3, vcc\n\tv_cndmask_b32_e32 %1, %4, %7, vcc"
-      : "=&v"(rl), "=v"(rh) : "v"(__double2loint(b)), "v"(__double2loint(a)), "v"(__double2hiint(b)), "n"(LO), "n"(HI), "v"(__double2hiint(a)) : "vcc");
-  return __hiloint2double(rh, rl);
-}
 // g + a * (value of x in lane I of THIS lane's half-wave): how the two-env constraint pass hands a row's change to the other rows of
 // its env (lanes 0..31 = env 0, 32..63 = env 1): two v_readlane, two moves and a select build the per-half operand, then the
 // multiply-add (6 VALU). Both lanes are read BEFORE the select (a `h1 ? rdlane : rdlane` compiles to exec-mask branches: +6 us on the
@@ -342,11 +328,6 @@ template <class T> NM_FN V<T> sel_mask(uint64_t m, const V<T>& a, const V<T>& b)
   return r;
 }
 NM_FN uint64_t mask_shl(uint64_t m, int k) { return m << k; }
-template <uint32_t LO, uint32_t HI, class T> NM_FN V<T> sel_lanes(const V<T>& a, const V<T>& b) {
-  V<T> r;
-  for (int i = 0; i < NM_WAVE; i++) r.v[i] = ((i < 32 ? LO >> i : HI >> (i - 32)) & 1u) ? a.v[i] : b.v[i];
-  return r;
-}
 template <int I, class T> NM_FN V<T> fma_half_lane(const V<T>& a, const V<T>& x, const V<T>& g, const VB&) {
   V<T> r;
   for (int i = 0; i < NM_WAVE; i++) r.v[i] = a.v[i] * x.v[(i & 32) + I] + g.v[i];
