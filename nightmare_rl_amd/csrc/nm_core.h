@@ -1150,6 +1150,7 @@ template <class real> NM_FN int support_exhaustive(const Model<real>& M, const r
 }
 template <class real> NM_FN real hull_tie_tol() { return sizeof(real) == 8 ? real(1e-13) : real(4e-7); }  // metres; >> rounding of ld.v
 constexpr int kMaxHop = 3;
+template <class real> constexpr real kObbSlack() { return real(1e-5); }   // metres; >> the float32 rounding of the box and of the hull vertices
 
 // Floor (z = 0) against the convex hulls of base_link and the six tibias. Like mjc_support, the search for the
 // support vertex is warm-started: lanes 0..maxnbr-1 evaluate the hull neighbours of last time's support vertex and lane
@@ -1211,6 +1212,17 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
   for (int g = 0; g < kNCOL; g++) {
     const real tol = hull_tie_tol<real>();
     if (near[g] && wany(nbl & (nb[g] >= 0) & (val[g] >= vr(sv[g] - tol)))) {
+      // Before searching: a mesh whose oriented bounding box is clear of the floor cannot touch it, whichever vertex is its support
+      // vertex - no walk, no exhaustive scan, the warm start stays. (The bounding SPHERE of the base reaches the floor whenever the
+      // robot stands, and two of its bottom vertices lie 28 um apart: without this test a level base ties and takes the exhaustive
+      // scan in every forward pass - 2.0 per env-step in the standing regime, profiles/r05_fallback_study.txt.)
+      {
+        const real* cc = M.colc + kColN * g;
+        real top = ldv[g][0] * cc[8] + ldv[g][1] * cc[9] + ldv[g][2] * cc[10];     // support value of the box along -normal
+#pragma unroll
+        for (int a = 0; a < 3; a++) top += cc[20 + a] * vabs(ldv[g][0] * cc[11 + 3 * a] + ldv[g][1] * cc[12 + 3 * a] + ldv[g][2] * cc[13 + 3 * a]);
+        if (uniform(pz[g] - top > kObbSlack<real>())) { near[g] = false; continue; }
+      }
       // Hill climbing on the hull graph (what mjc_support's warm start does): while a neighbour is clearly higher, move to
       // the highest one. A vertex that beats all its neighbours by a margin is the support vertex of a convex hull. Near
       // ties (and walks longer than kMaxHop) go to the exhaustive scan, whose lowest-index rule is the reference behaviour.
@@ -1239,6 +1251,9 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
         const int held = si;                    // the vertex whose ring the lanes hold
         si = support_exhaustive(M, ld, nvert, vadr);
         sh.hcache[7] += 1;
+#ifdef NM_MEASURE
+        sh.nhop += g == 0 ? 1000 : 100000;   // which mesh fell back, for scripts/fallback_study.py (debug slot 159)
+#endif
         if (si != held) {                       // a tie fallback usually confirms the vertex it started from: no second dependent gather then
           hull_ring(M, vadr + si, si, nb[g], vv[g]);
           val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
@@ -1269,6 +1284,17 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       vr d2 = dd[0] * dd[0] + dd[1] * dd[1] + dd[2] * dd[2];
       const VB ok = nbl & (nb[g] >= 0) & (val[g] > vr(pz[g])) & !(d2 < vr(tol * tol));     // |.| < tol without the square root
       const uint64_t m = ballot(ok);
+      if (m == 0) {
+        // The support vertex alone (every foot of a standing or walking robot: its penetrating hull neighbours lie within the
+        // tolerance of it): its lane stores the contact, nothing is ranked.
+        const VB wr = (lane == kSelfLane) & VB(total < kMaxConBig);
+        const int sl = vmin(total, kMaxConBig - 1);
+        stsv(sh.cpos(), V<int>(sl * 3), pnt[0], wr);
+        stsv(sh.cpos(), V<int>(sl * 3 + 1), pnt[1], wr);
+        stsv(sh.cpos(), V<int>(sl * 3 + 2), pnt[2] - real(0.5) * dist, wr);
+        stsv(sh.cdist(), V<int>(sl), vr(dist), wr);
+        stsv(sh.cleg(), V<int>(sl), V<int>(g - 1), wr);
+      } else {
       nextra = vmin(popc64(m), 3);
       const V<int> rank = lane_rank(m);
       const VB self = lane == kSelfLane;
@@ -1281,6 +1307,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       stsu(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * cd, wr, sh.sink);
       stsu(sh.cdist(), sl, cd, wr, sh.sink);
       stsu(sh.cleg(), sl, V<int>(g - 1), wr, sh.sink);
+      }
       // (a floor contact's normal (0,0,1) and "no first body" are not stored here: only the rare constraint paths read them, and
       // those fill them in first - floor_frames())
     }
