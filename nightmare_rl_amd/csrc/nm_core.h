@@ -81,6 +81,7 @@ template <class real> struct Model {
   // terms the reference config ships with scale 0 (config.py:88-95) and contact modes other than 1 (config.py:17-21)
   int rew_extra;           // any of ang_vel_xy base_height dof_vel feet_air_time feet_contact_forces lin_vel_z stand_still is in the table
   int tibia_mode, body_mode;
+  int collide_batch_min;   // floor contacts of an env go out in one batched pass from this many touching meshes on (stage_collide); 3
   real tibia_max, body_max, base_h_target, max_contact_force;
 };
 
@@ -1158,14 +1159,22 @@ template <class real> constexpr real kObbSlack() { return real(1e-5); }   // met
 // does the mesh fall back to the exhaustive scan - so the result is always the exhaustive one (lowest index on ties).
 // The same neighbour data then yields the <= 3 extra plane-mesh contacts.
 constexpr int kSelfLane = 63;
+// A plane-mesh contact brings up to three more: penetrating hull neighbours of the support vertex that lie >= tol_planemesh x rbound from it.
+// When even the farthest neighbour of the vertex is nearer than that - every vertex of a foot tip (neighbours within 3 mm, tolerance 37 mm) -
+// the contact is a lone one whatever the pose: the table holds, per vertex, slack = 0.999 tol - 1.00001 max |neighbour - vertex| in units of
+// 2^-20 m (an integer, exact in float32; < 0 = never), and 0.5 |dist| < slack certifies it (the first contact sits 0.5 dist off the vertex).
+constexpr int kSlackScale = 1 << 20;
+constexpr int kBatchLane0 = kSelfLane + 1 - kNCOL;   // the batched emission puts mesh g on lane kBatchLane0 + g (those lanes hold the mesh's support vertex)
 // lanes 0..maxnbr-1: the hull neighbours of global vertex gv (id -1 = none), lane 63: the vertex itself (local id `self`)
-template <class real> NM_FN void hull_ring(const Model<real>& M, int gv, int self, V<int>& nbg, V<real>* v) {
+// lanes maxnbr.. of nbg: the vertex's `lone-contact slack` (its table entry's fourth word, see kSlackScale) - neighbour ids are read under
+// `lane < maxnbr` only
+template <class real> NM_FN void hull_ring(const Model<real>& M, int gv, V<int>& nbg, V<real>* v) {
   const V<int> lane = lane_id();
   const VB nbl = lane < M.maxnbr;
   V<real> o[4];
   gld4(M.hullnv, (sel(nbl, lane, V<int>(M.maxnbr)) + gv * (M.maxnbr + 1)) * 4, o);
   v[0] = o[0]; v[1] = o[1]; v[2] = o[2];
-  nbg = sel(lane == kSelfLane, V<int>(self), sel(nbl, to_int(o[3]), V<int>(-1)));
+  nbg = to_int(o[3]);
 }
 // the seven ring gathers of one env (L2 round trips): issued apart from their use, so that a wave can have both of its envs' in flight
 template <class real> struct Rings {
@@ -1178,7 +1187,7 @@ template <class real> NM_FN void collide_rings(const Sh<real>& sh, const Model<r
   for (int g = 0; g < kNCOL; g++) {
     const int vadr = (int)M.colc[kColN * g + 6];
     r.cur[g] = uniform(sh.hcache[g]);
-    hull_ring(M, vadr + r.cur[g], r.cur[g], r.nb[g], r.vv[g]);
+    hull_ring(M, vadr + r.cur[g], r.nb[g], r.vv[g]);
   }
 }
 template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& M, int* dropped, Rings<real>& rg, bool pairs = true) {
@@ -1240,7 +1249,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
         wmaxfirst(sel(nbv, val[g], vr(real(-1e30))), &bv, &lbest);
         si = rdlane(nb[g], lbest);
         NM_BSTAMP(12);
-        hull_ring(M, vadr + si, si, nb[g], vv[g]);
+        hull_ring(M, vadr + si, nb[g], vv[g]);
         val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
         sv[g] = rdlane(val[g], kSelfLane);
         NM_BSTAMP(14);
@@ -1255,7 +1264,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
         sh.nhop += g == 0 ? 1000 : 100000;   // which mesh fell back, for scripts/fallback_study.py (debug slot 159)
 #endif
         if (si != held) {                       // a tie fallback usually confirms the vertex it started from: no second dependent gather then
-          hull_ring(M, vadr + si, si, nb[g], vv[g]);
+          hull_ring(M, vadr + si, nb[g], vv[g]);
           val[g] = ld[0] * vv[g][0] + ld[1] * vv[g][1] + ld[2] * vv[g][2];
           sv[g] = rdlane(val[g], kSelfLane);
         }
@@ -1266,14 +1275,62 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
   }
   NM_BSTAMP(12);
   int total = 0;   // contacts found so far (not capped)
+  unsigned hitbits = 0;      // bit g: mesh g touches the floor
+#pragma unroll
+  for (int g = 0; g < kNCOL; g++) hitbits |= (uniform(near[g] && pz[g] - sv[g] < real(0)) ? 1u : 0u) << g;
+  const int nhit = popc64(hitbits);
+  // The standing / walking robot: several feet on the floor, each a lone contact at its support vertex (certified from the table, above).
+  // Those go out together, mesh g on lane kBatchLane0 + g: one pass of per-lane frames instead of one pass per mesh.
+  bool batch = false;
+  if (nhit >= M.collide_batch_min) {
+    const uint64_t hitm = (uint64_t)hitbits << kBatchLane0;
+    vr X[3] = {vv[kNCOL - 1][0], vv[kNCOL - 1][1], vv[kNCOL - 1][2]}, svl = val[kNCOL - 1];
+    V<int> slackl = nb[kNCOL - 1];
+    V<int> lb = lane;
+#pragma unroll
+    for (int g = kNCOL - 2; g >= 0; g--) {
+      order_after(lb, X[0]);      // one lane mask alive at a time (7 at once cost 14 spilled SGPRs)
+      const VB mg = lb == kBatchLane0 + g;
+      X[0] = sel(mg, vv[g][0], X[0]); X[1] = sel(mg, vv[g][1], X[1]); X[2] = sel(mg, vv[g][2], X[2]);
+      svl = sel(mg, val[g], svl);
+      slackl = sel(mg, nb[g], slackl);
+    }
+    const VB ml = lane >= kBatchLane0;
+    const V<int> gl = sel(ml, lane - kBatchLane0, V<int>(0));
+    const vr pzl = ldsv(sh.colp, gl * 3 + 2) + bz;
+    const vr distl = pzl - svl;
+    const VB wr = in_mask(hitm);
+    const VB lone = distl * real(-0.5 * kSlackScale) < to_real<real>(slackl);
+    if (!wany(wr & !lone)) {
+      vr Rl[9], pl[2], pnt[3];
+#pragma unroll
+      for (int j = 0; j < 9; j++) Rl[j] = ldsv(sh.colR, gl * 9 + j);
+#pragma unroll
+      for (int j = 0; j < 2; j++) pl[j] = ldsv(sh.colp, gl * 3 + j);
+      matvec3(pnt, Rl, X);
+      pnt[0] = pnt[0] + pl[0]; pnt[1] = pnt[1] + pl[1]; pnt[2] = pnt[2] + ldsv(sh.colp, gl * 3 + 2);
+      const V<int> slot = lane_rank(hitm);
+      const V<int> sl = sel(wr, slot, V<int>(0));
+      stsv(sh.cpos(), sl * 3, pnt[0], wr);
+      stsv(sh.cpos(), sl * 3 + 1, pnt[1], wr);
+      stsv(sh.cpos(), sl * 3 + 2, pnt[2] - real(0.5) * distl, wr);
+      stsv(sh.cdist(), sl, distl, wr);
+      stsv(sh.cleg(), sl, gl - 1, wr);
+      stsv(sh.cstart, gl, slot, ml);
+      stsv(sh.ccnt, gl, sel(wr, V<int>(1), V<int>(0)), ml);
+      total = nhit;
+      batch = true;
+    }
+  }
+  if (!batch) {
 #pragma unroll
   for (int g = 0; g < kNCOL; g++) {
     const real* R = sh.colR + 9 * g;
     const real* p = sh.colp + 3 * g;
     const real dist = pz[g] - sv[g];
-    const bool hitg = near[g] && dist < real(0);
+    const bool hitg = (hitbits >> g) & 1;
     int nextra = 0;
-    if (uniform(hitg)) {   // most meshes do not touch the floor in a given substep: their contact emission is skipped, not masked
+    if (hitg) {   // most meshes do not touch the floor in a given substep: their contact emission is skipped, not masked
       vr pnt[3];
       matvec3(pnt, R, vv[g]);
       pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
@@ -1316,6 +1373,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     sh.cstart[g] = c0;
     sh.ccnt[g] = c1 - c0;
     total += ng;
+  }
   }
   const int ncon = vmin(total, kMaxConBig);
   *dropped += total - ncon;

@@ -51,6 +51,7 @@ inline void body_inertia6(const double* iquat, const double* diag, double* out) 
   out[0] = I[0]; out[1] = I[4]; out[2] = I[8]; out[3] = I[1]; out[4] = I[2]; out[5] = I[5];
 }
 
+constexpr double kTolPlaneMesh = 0.3;   // MuJoCo's mjTOLPLANEMESH [3P]: extra plane-mesh contacts keep this x rbound from the first one
 template <class real> struct Tables {
   std::vector<real> legc, basec, colc, hullv, footc, qpos0;
   std::vector<real> hullnv;
@@ -111,9 +112,17 @@ template <class real> struct Tables {
             row[4 * j + 3] = (real)n;
           }
           for (int k = 0; k < 3; k++) row[4 * NM_HULL_MAXNBR + k] = (real)nm_hull_vert[vadr + i][k];
-          int deg = 0;
-          for (int j = 0; j < NM_HULL_MAXNBR; j++) deg += nm_hull_nbr[vadr + i][j] >= 0;
-          row[4 * NM_HULL_MAXNBR + 3] = (real)(i + 1024 * deg);   // own local id (< 1024) and degree, exact in fp32
+          // the vertex's lone-contact slack (nm_core.h kSlackScale): 0.999 tol_planemesh rbound - 1.00001 max |neighbour - vertex|, in 2^-20 m
+          double far = 0;
+          for (int j = 0; j < NM_HULL_MAXNBR; j++) {
+            const int n = nm_hull_nbr[vadr + i][j];
+            if (n < 0) continue;
+            double d2 = 0;
+            for (int k = 0; k < 3; k++) { const double d = (double)nm_hull_vert[vadr + n][k] - (double)nm_hull_vert[vadr + i][k]; d2 += d * d; }
+            far = std::max(far, std::sqrt(d2));
+          }
+          const double slack = (0.999 * kTolPlaneMesh * (double)nm_col_rbound[g] - 1.00001 * far) * (double)nm::kSlackScale;
+          row[4 * NM_HULL_MAXNBR + 3] = (real)std::floor(std::min(std::max(slack, -1.0), 8388607.0));
         }
       }
     }
@@ -144,7 +153,7 @@ template <class real> struct Tables {
     M.solref_B = (real)(2.0 / std::fmax(1e-15, dmax * tc));
     M.si_d0 = (real)nm_solimp[0]; M.si_dmax = (real)nm_solimp[1]; M.si_width = (real)nm_solimp[2]; M.si_mid = (real)nm_solimp[3]; M.si_power = (real)nm_solimp[4];
     M.pgs_scale = (real)(1.0 / (NM_MEANINERTIA * NM_NV));
-    M.pgs_tol = (real)NM_TOLERANCE; M.noslip_tol = (real)NM_NOSLIP_TOLERANCE; M.tol_planemesh = (real)0.3;
+    M.pgs_tol = (real)NM_TOLERANCE; M.noslip_tol = (real)NM_NOSLIP_TOLERANCE; M.tol_planemesh = (real)kTolPlaneMesh;
     M.pgs_iters = NM_ITERATIONS; M.noslip_iters = NM_NOSLIP_ITERATIONS;
     M.mpr_iters = 50; M.mpr_tol = (real)1e-6;  // MuJoCo 3.1.2 defaults opt.mpr_iterations / opt.mpr_tolerance
     double dt = NM_TIMESTEP * cfg.decimation;                       // env.py:99
@@ -162,6 +171,8 @@ template <class real> struct Tables {
     for (int k : {nm::R_ANG_VEL_XY, nm::R_BASE_HEIGHT, nm::R_DOF_VEL, nm::R_FEET_AIR_TIME, nm::R_FEET_CONTACT, nm::R_LIN_VEL_Z, nm::R_STAND_STILL})
       if (cfg.rew_scales[k] != 0) M.rew_extra = 1;
     M.tibia_mode = cfg.tibia_contact_mode; M.body_mode = cfg.body_contact_mode;
+    M.collide_batch_min = 3;
+    if (const char* e = std::getenv("NM_COLLIDE_BATCH_MIN")) M.collide_batch_min = std::atoi(e);   // tests: 99 = never batch, 1 = whenever certified
     M.tibia_max = (real)cfg.tibia_max_contact_force; M.body_max = (real)cfg.body_max_contact_force;
     M.base_h_target = (real)cfg.base_height_target; M.max_contact_force = (real)cfg.max_contact_force;
   }

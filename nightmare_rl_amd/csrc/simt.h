@@ -183,6 +183,9 @@ NM_FN bool wany(bool c) { return __ballot(c) != 0ull; }
 NM_FN int lane_rank(uint64_t m) { return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); }
 NM_FN int popc64(uint64_t m) { return __popcll(m); }
 NM_FN uint64_t ballot(bool c) { return __ballot(c); }
+NM_FN bool in_mask(uint64_t m) { return __builtin_amdgcn_inverse_ballot_w64(m); }   // this lane's bit of a wave-uniform mask
+// scheduling fence: what is computed from `a` afterwards cannot be issued before `dep` exists (keeps short-lived lane masks short-lived)
+template <class T> NM_FN void order_after(int& a, const T& dep) { asm volatile("" : "+v"(a) : "v"(dep)); }
 // argmax with lowest-index tie break; returns uniform (value, index)
 template <class T> NM_FN void wargmax(T val, int idx, T* best, int* ibest) {
 #define NM_AM_STEP(CTRL)                                                   \
@@ -367,6 +370,8 @@ NM_FN bool wany(const VB& c) { for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) ret
 NM_FN V<int> lane_rank(uint64_t m) { V<int> r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = __builtin_popcountll(m & ((1ull << i) - 1ull)); return r; }
 NM_FN int popc64(uint64_t m) { return __builtin_popcountll(m); }
 NM_FN uint64_t ballot(const VB& c) { uint64_t m = 0; for (int i = 0; i < NM_WAVE; i++) if (c.v[i]) m |= 1ull << i; return m; }
+NM_FN VB in_mask(uint64_t m) { VB r; for (int i = 0; i < NM_WAVE; i++) r.v[i] = (m >> i) & 1; return r; }
+template <class T> NM_FN void order_after(V<int>&, const V<T>&) {}
 template <class T> NM_FN void wargmax(V<T> val, V<int> idx, T* best, int* ibest) {
   T bv = val.v[0]; int bi = idx.v[0];
   for (int i = 1; i < NM_WAVE; i++)

@@ -6,9 +6,10 @@ from nightmare_rl_amd.envs.nightmare_v3_config import NightmareV3Config
 from nightmare_rl_amd.envs.nightmare_v3_env import NightmareV3Env
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 cfg = NightmareV3Config(); cfg.env.num_envs = N
-acts = (torch.rand(16, N, 18, generator=torch.Generator().manual_seed(0)) * 2 - 1).cuda()
+scale = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0     # 0.12 = the standing regime
+acts = ((torch.rand(16, N, 18, generator=torch.Generator().manual_seed(0)) * 2 - 1) * scale).cuda()
 env = NightmareV3Env(cfg, seed=0); env.reset()
-for i in range(300): env.step(acts[i % 16])
+for i in range(300 if scale == 1.0 else 1500): env.step(acts[i % 16])
 out = (C.c_ulonglong * 16)()
 env._L.nm_read_stamps(out, 1)
 K = 200
@@ -27,5 +28,5 @@ tot = sum(out[:16])
 for k, n in enumerate(names):
     print(f"{n:28s} {out[k] / K / waves:10.0f} ticks/wave/step  {100.0 * out[k] / tot:5.1f} %")
 c = env.counters()
-print("fallbacks per wave-step:", c["hull_search_fallbacks"] / (500 * waves))
+print("fallbacks per wave-step:", c["hull_search_fallbacks"] / (env.common_step_counter * waves))
 print(f"{'total':28s} {tot / K / waves:10.0f} ticks/wave/step (s_memtime ticks)")

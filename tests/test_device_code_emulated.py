@@ -170,6 +170,33 @@ def test_envs_per_wave_does_not_change_results(emul):
     assert emul.lib().emu_together_count() - before > 50
 
 
+def test_batched_floor_contacts_equal_the_mesh_by_mesh_emission(emul, monkeypatch):
+    """From three touching meshes on, lone support-vertex contacts (certified by the table's per-vertex slack) leave stage B in one batched
+    pass, mesh g on lane 57 + g. NM_COLLIDE_BATCH_MIN (read when an env is created) = 99 never batches, = 1 batches whenever the
+    certificate holds: the two must agree bitwise, on a standing robot (small actions: 5-6 feet down) and on a flailing one."""
+    N, T = 6, 70
+    for scale, seed in ((0.12, 5), (1.0, 6)):
+        rng = np.random.default_rng(seed)
+        monkeypatch.setenv("NM_COLLIDE_BATCH_MIN", "99")
+        e1 = emul.EmulEnv(N, double=False, seed=4, envs_per_wave=2)
+        monkeypatch.setenv("NM_COLLIDE_BATCH_MIN", "1")
+        e2 = emul.EmulEnv(N, double=False, seed=4, envs_per_wave=2)
+        monkeypatch.delenv("NM_COLLIDE_BATCH_MIN")
+        e3 = emul.EmulEnv(N, double=False, seed=4, envs_per_wave=1)          # the shipped threshold, one env per wave
+        most = 0
+        for t in range(T):
+            a = (rng.uniform(-1, 1, (N, 18)) * scale).astype(np.float32)
+            o1, o2, o3 = e1.step(a), e2.step(a, want_dbg=True), e3.step(a)
+            for x, y, z in zip(o1, o2, o3):
+                np.testing.assert_array_equal(x, y)
+                np.testing.assert_array_equal(x, z)
+            most += int((e2.dbg[:, 160] >= 3).sum())      # envs whose last forward pass had three or more contacts
+        for k in ("qpos", "qvel", "qwarm"):
+            np.testing.assert_array_equal(e1.get(k), e2.get(k))
+            np.testing.assert_array_equal(e1.get(k), e3.get(k))
+        assert most > (200 if scale < 1 else 20), most     # the batched pass had work to do
+
+
 def test_noise_generator_matches_oracle(emul, oracle_mod):
     """Counter-RNG observation noise (no injected uniforms): device algorithm == oracle, keyed by global env id and step."""
     N, off = 4, 1000
