@@ -12,8 +12,8 @@ echo "== bench"; python bench.py > $OUT/${TAG}_bench.json.log 2>&1; tail -c 600 
 python bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/${TAG}_bench_driverargs.json.log 2>&1
 echo "== train 40 iterations + play"; rm -rf logs; python train.py -e 4096 --iters 40 > $OUT/${TAG}_train40.log 2>&1; grep -E "^it +(1|20|39)/" $OUT/${TAG}_train40.log
 python scripts/play.py --log-root logs/nightmare_v3 -e 64 --steps 400 > $OUT/${TAG}_play.log 2>&1; tail -4 $OUT/${TAG}_play.log
-echo "== curves (HIP side; the CPU side of the same size: profiles/r04_curve_cpu_runs.json (round-4 tables: see DESIGN 6.3), tests/tools/curve_vs_cpu.py --kinds cpu in the build container)"
-python tests/tools/curve_vs_cpu.py --kinds hip --envs 4096 --iters 150 --seeds 3 --merge profiles/r04_curve_cpu_runs.json --out $OUT/${TAG}_curve_vs_cpu.json > $OUT/${TAG}_curve.log 2>&1; grep -E "^it +[0-9]+  mean" $OUT/${TAG}_curve.log
+echo "== curves (HIP side; the CPU side of the same size: profiles/r05_curve_cpu_runs.json (round-5 tables: see DESIGN 6.3), tests/tools/curve_vs_cpu.py --kinds cpu in the build container)"
+python tests/tools/curve_vs_cpu.py --kinds hip --envs 4096 --iters 150 --seeds 3 --merge profiles/r05_curve_cpu_runs.json --out $OUT/${TAG}_curve_vs_cpu.json > $OUT/${TAG}_curve.log 2>&1; grep -E "^it +[0-9]+  mean" $OUT/${TAG}_curve.log
 echo "== one-launch rollout"; python scripts/rolloutbench.py 4096 80 > $OUT/${TAG}_rolloutbench.txt 2>&1; grep -v amdgpu $OUT/${TAG}_rolloutbench.txt
 python scripts/rolloutwaves.py 4096 80 > $OUT/${TAG}_rolloutwaves.txt 2>&1; grep -v amdgpu $OUT/${TAG}_rolloutwaves.txt
 cd /tmp && export TMPDIR=/tmp
