@@ -196,6 +196,14 @@ template <class A, class B, class C> NM_FN void matvec3(A* r, const B* m, const 
   A x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2], y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2], z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
+// the same with the order of the roundings written down (fma(m2, v2, fma(m1, v1, m0 v0))): where two code paths must agree bit for bit on
+// the device, the compiler must not be the one who picks which product is rounded first
+template <class A, class B, class C> NM_FN void matvec3_fma(A* r, const B* m, const C* v) {
+  A x = vfma(A(m[2]), A(v[2]), vfma(A(m[1]), A(v[1]), A(m[0]) * A(v[0])));
+  A y = vfma(A(m[5]), A(v[2]), vfma(A(m[4]), A(v[1]), A(m[3]) * A(v[0])));
+  A z = vfma(A(m[8]), A(v[2]), vfma(A(m[7]), A(v[1]), A(m[6]) * A(v[0])));
+  r[0] = x; r[1] = y; r[2] = z;
+}
 template <class A, class B, class C> NM_FN void matmul3(A* r, const B* a, const C* b) {
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -1307,7 +1315,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
       for (int j = 0; j < 9; j++) Rl[j] = ldsv(sh.colR, gl * 9 + j);
 #pragma unroll
       for (int j = 0; j < 2; j++) pl[j] = ldsv(sh.colp, gl * 3 + j);
-      matvec3(pnt, Rl, X);
+      matvec3_fma(pnt, Rl, X);
       pnt[0] = pnt[0] + pl[0]; pnt[1] = pnt[1] + pl[1]; pnt[2] = pnt[2] + ldsv(sh.colp, gl * 3 + 2);
       const V<int> slot = lane_rank(hitm);
       const V<int> sl = sel(wr, slot, V<int>(0));
@@ -1332,7 +1340,7 @@ template <class real> NM_FN void stage_collide(Sh<real>& sh, const Model<real>& 
     int nextra = 0;
     if (hitg) {   // most meshes do not touch the floor in a given substep: their contact emission is skipped, not masked
       vr pnt[3];
-      matvec3(pnt, R, vv[g]);
+      matvec3_fma(pnt, R, vv[g]);
       pnt[0] = pnt[0] + p[0]; pnt[1] = pnt[1] + p[1]; pnt[2] = pnt[2] + p[2];
       const real first[3] = {rdlane(pnt[0], kSelfLane), rdlane(pnt[1], kSelfLane), rdlane(pnt[2], kSelfLane) - real(0.5) * dist};
       // up to three more: penetrating hull neighbours of the support vertex, >= tolerance from the first contact
