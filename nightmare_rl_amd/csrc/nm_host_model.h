@@ -101,6 +101,7 @@ template <class real> struct Tables {
       for (int j = 0; j < 3; j++) hullv[4 * i + j] = (real)nm_hull_vert[i][j];
     {  // ring table: vertex -> (neighbour xyz, neighbour local id) x maxnbr, then the vertex itself
       const int S = NM_HULL_MAXNBR + 1;
+      static_assert(NM_HULL_MAXNBR <= nm::kBatchLane0, "lanes kBatchLane0.. of a ring must hold the vertex itself (stage_collide's batched emission)");
       hullnv.assign((size_t)NM_NHULLVERT * S * 4, real(0));
       for (int g = 0; g < nm::kNCOL; g++) {
         const int vadr = nm_col_vadr[g], nv = nm_col_nvert[g];
