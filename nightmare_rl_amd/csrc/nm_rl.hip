@@ -45,6 +45,9 @@ __global__ void __launch_bounds__(kGaeThreads) k_gae_adv(const float* __restrict
   float s1 = 0.0f, s2 = 0.0f;
   if (e < N) {
     float adv = 0.0f, next = last_values[e];
+    // (the loads of a step do not depend on the recurrence: unrolled, eight steps' loads are in flight at once instead of one HBM round
+    // trip per step - 80 of them in a row were the kernel's 29 us)
+#pragma unroll 8
     for (int s = T - 1; s >= 0; s--) {
       const size_t i = (size_t)s * N + e;
       const float live = 1.0f - (float)dones[i];
