@@ -61,6 +61,45 @@ def _time_oracle(n, threads, seconds, physics_only=False):
     return n * k / (time.perf_counter() - t0), k
 
 
+def live_pmc(E):
+    """HBM-side bytes per launch and VALU issue of the step kernel, measured DURING this run (the line carried the builder's
+    box's counters): rocprofv3 --pmc passes over scripts/pmcrun.py (the same kernel, 4096 envs, 360 random-action steps) as CHILD processes -
+    the profiler cannot attach to this one -, one pass per counter group with --kernel-trace only, as MI355X_MICROARCH.md prescribes. Medians
+    over the launches after the first quarter. None when rocprofv3 is missing or a pass fails (the committed profile is used then)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None
+    out = tempfile.mkdtemp(prefix="nm_bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    med = {}
+    try:
+        for k, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"], ["GRBM_GUI_ACTIVE"])):
+            d = os.path.join(out, f"p{k}")
+            r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", d, "-o", "run", "--", "python3", os.path.join(ROOT, "scripts", "pmcrun.py"), "4096"],
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None
+            vals = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "k_env_step" in row["Kernel_Name"]:
+                        vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
+            for c in ctrs:
+                v = sorted(vals[c][len(vals[c]) // 4:])
+                med[c] = v[len(v) // 2]
+        simd_cycles = med["GRBM_GUI_ACTIVE"] / 8 * 1024          # the counter is summed over the 8 XCDs; 1024 SIMDs
+        return {"FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"],
+                "hbm_bytes_per_launch": (med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0 * (E / 4096.0),
+                "hbm_bytes_per_launch_if_reads_are_half_counted": (2 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0 * (E / 4096.0),
+                "valu": {"definition": "SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)", "frac_of_4_cycle_issue": med["SQ_INSTS_VALU"] * 4 / simd_cycles,
+                         "frac_of_simd32_2_cycle_issue": med["SQ_INSTS_VALU"] * 2 / simd_cycles, "insts_per_wave": med["SQ_INSTS_VALU"] / max(med["SQ_WAVES"], 1.0)}}
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
 def cpu_baseline(envs=4096):
     """The CPU oracle (a port: MuJoCo itself is not installable) on this box's host cores: the same workload (N envs, random
     actions, full step()) on a bounded sample, plus the grid SURVEY 8(d) / BASELINE.md ask for - N in {1, N} x T in {1, all cores},
@@ -84,6 +123,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--envs-per-gpu", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not start the rocprofv3 --pmc child passes (roofline.traffic / valu then come from profiles/)")
     args = ap.parse_args()
     if args.gpus is None:
         args.gpus = int(os.environ.get("WORLD_SIZE", "1"))
@@ -457,6 +497,14 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(E)
+        if not args.no_cpu_baseline and not args.no_live_pmc and world == 1 and E == 4096:
+            # after every timed leg: the counters of THIS box, this run (child processes; this process issues nothing meanwhile)
+            lp = live_pmc(E)
+            if lp:
+                out["roofline"]["traffic"] = lp["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over scripts/pmcrun.py (KB x 1024; "
+                                                     f"reads {lp['FETCH_SIZE_KB']:.0f} KB, possibly counted at half on gfx950: upper bound {lp['hbm_bytes_per_launch_if_reads_are_half_counted']:.0f} B; writes {lp['WRITE_SIZE_KB']:.0f} KB)")
+                out["roofline"]["valu"] = dict(lp["valu"], source="measured in this run (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / GRBM_GUI_ACTIVE child passes)")
     if world > 1:
         # BASELINE config 5 at N > 1: the full PPO loop, `E` envs per rank, data-parallel update (one RCCL all-reduce of
         # gradient | KL per mini-batch, inside the update's graph), whole-job env-steps/s. Runs LAST and under a deadline: the headline
