@@ -74,7 +74,8 @@ def live_pmc(E):
     env = dict(os.environ, TMPDIR="/tmp")
     med = {}
     try:
-        for k, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"], ["GRBM_GUI_ACTIVE"])):
+        lanes_ctrs = ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"]
+        for k, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"], ["GRBM_GUI_ACTIVE"], lanes_ctrs)):
             d = os.path.join(out, f"p{k}")
             r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", d, "-o", "run", "--", "python3", os.path.join(ROOT, "scripts", "pmcrun.py"), "4096"],
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
@@ -89,7 +90,10 @@ def live_pmc(E):
                 v = sorted(vals[c][len(vals[c]) // 4:])
                 med[c] = v[len(v) // 2]
         simd_cycles = med["GRBM_GUI_ACTIVE"] / 8 * 1024          # the counter is summed over the 8 XCDs; 1024 SIMDs
-        return {"FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"],
+        lanes = med["SQ_THREAD_CYCLES_VALU"] / max(med["SQ_ACTIVE_INST_VALU"], 1.0)
+        flop = (med["SQ_INSTS_VALU_ADD_F32"] + med["SQ_INSTS_VALU_MUL_F32"] + 2 * med["SQ_INSTS_VALU_FMA_F32"] + med["SQ_INSTS_VALU_TRANS_F32"]) * lanes * (E / 4096.0)
+        return {"fp32_flop_per_launch": flop, "active_lanes_per_valu_instruction": lanes,
+                "FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0 * (E / 4096.0),
                 "hbm_bytes_per_launch_if_reads_are_half_counted": (2 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0 * (E / 4096.0),
                 "valu": {"definition": "SQ_INSTS_VALU x 4 cycles / (GRBM_GUI_ACTIVE per XCD x 1024 SIMDs)", "frac_of_4_cycle_issue": med["SQ_INSTS_VALU"] * 4 / simd_cycles,
@@ -505,6 +509,11 @@ def main():
                 out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over scripts/pmcrun.py (KB x 1024; "
                                                      f"reads {lp['FETCH_SIZE_KB']:.0f} KB, possibly counted at half on gfx950: upper bound {lp['hbm_bytes_per_launch_if_reads_are_half_counted']:.0f} B; writes {lp['WRITE_SIZE_KB']:.0f} KB)")
                 out["roofline"]["valu"] = dict(lp["valu"], source="measured in this run (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / GRBM_GUI_ACTIVE child passes)")
+                tf = lp["fp32_flop_per_launch"] / k_avg / 1e12
+                out["roofline"]["valu_fp32"] = {"bound": "valu-f32", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "fp32_flop_per_launch": lp["fp32_flop_per_launch"],
+                                                "active_lanes_per_valu_instruction": lp["active_lanes_per_valu_instruction"],
+                                                "source": "measured in this run: (add + mul + 2 fma + trans f32 wave-instructions) x active lanes per VALU instruction "
+                                                          "(SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU), rocprofv3 --pmc child pass; over this run's kernel time"}
     if world > 1:
         # BASELINE config 5 at N > 1: the full PPO loop, `E` envs per rank, data-parallel update (one RCCL all-reduce of
         # gradient | KL per mini-batch, inside the update's graph), whole-job env-steps/s. Runs LAST and under a deadline: the headline
