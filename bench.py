@@ -78,7 +78,7 @@ def live_pmc(E):
         for k, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"], ["GRBM_GUI_ACTIVE"], lanes_ctrs)):
             d = os.path.join(out, f"p{k}")
             r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", d, "-o", "run", "--", "python3", os.path.join(ROOT, "scripts", "pmcrun.py"), "4096"],
-                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                               cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
                 return None
             vals = {}
