@@ -75,24 +75,33 @@ def live_pmc(E):
     med = {}
     try:
         lanes_ctrs = ["SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32", "SQ_INSTS_VALU_FMA_F32", "SQ_INSTS_VALU_TRANS_F32"]
-        for k, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"], ["GRBM_GUI_ACTIVE"], lanes_ctrs)):
+        def one_pass(k, ctrs, script, pat, prefix=""):
             d = os.path.join(out, f"p{k}")
-            r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", d, "-o", "run", "--", "python3", os.path.join(ROOT, "scripts", "pmcrun.py"), "4096"],
+            r = subprocess.run([exe, "--kernel-trace", "--output-format", "csv", "--pmc", *ctrs, "-d", d, "-o", "run", "--", "python3", os.path.join(ROOT, "scripts", script), "4096"],
                                cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
-                return None
+                raise RuntimeError("rocprofv3 pass failed")
             vals = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for row in csv.DictReader(open(f)):
-                    if "k_env_step" in row["Kernel_Name"]:
+                    if pat in row["Kernel_Name"]:
                         vals.setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
             for c in ctrs:
                 v = sorted(vals[c][len(vals[c]) // 4:])
-                med[c] = v[len(v) // 2]
+                med[prefix + c] = v[len(v) // 2]
+        for k, ctrs in enumerate((["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_INSTS_VALU", "SQ_WAVES"], ["GRBM_GUI_ACTIVE"], lanes_ctrs)):
+            one_pass(k, ctrs, "pmcrun.py", "k_env_step")
+        rollout = None
+        try:      # the one-launch rollout kernel's HBM side (4096 envs x 80 steps per launch, scripts/pmcrollout.py): two more passes
+            one_pass(5, ["FETCH_SIZE"], "pmcrollout.py", "k_env_rollout", "roll_")
+            one_pass(6, ["WRITE_SIZE"], "pmcrollout.py", "k_env_rollout", "roll_")
+            rollout = {"hbm_bytes_per_launch": (med["roll_FETCH_SIZE"] + med["roll_WRITE_SIZE"]) * 1024.0, "envs": 4096, "steps": 80}
+        except Exception:
+            rollout = None
         simd_cycles = med["GRBM_GUI_ACTIVE"] / 8 * 1024          # the counter is summed over the 8 XCDs; 1024 SIMDs
         lanes = med["SQ_THREAD_CYCLES_VALU"] / max(med["SQ_ACTIVE_INST_VALU"], 1.0)
         flop = (med["SQ_INSTS_VALU_ADD_F32"] + med["SQ_INSTS_VALU_MUL_F32"] + 2 * med["SQ_INSTS_VALU_FMA_F32"] + med["SQ_INSTS_VALU_TRANS_F32"]) * lanes * (E / 4096.0)
-        return {"fp32_flop_per_launch": flop, "active_lanes_per_valu_instruction": lanes,
+        return {"fp32_flop_per_launch": flop, "active_lanes_per_valu_instruction": lanes, "rollout": rollout,
                 "FETCH_SIZE_KB": med["FETCH_SIZE"], "WRITE_SIZE_KB": med["WRITE_SIZE"],
                 "hbm_bytes_per_launch": (med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0 * (E / 4096.0),
                 "hbm_bytes_per_launch_if_reads_are_half_counted": (2 * med["FETCH_SIZE"] + med["WRITE_SIZE"]) * 1024.0 * (E / 4096.0),
@@ -509,6 +518,10 @@ def main():
                 out["roofline"]["traffic_source"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over scripts/pmcrun.py (KB x 1024; "
                                                      f"reads {lp['FETCH_SIZE_KB']:.0f} KB, possibly counted at half on gfx950: upper bound {lp['hbm_bytes_per_launch_if_reads_are_half_counted']:.0f} B; writes {lp['WRITE_SIZE_KB']:.0f} KB)")
                 out["roofline"]["valu"] = dict(lp["valu"], source="measured in this run (rocprofv3 --pmc SQ_INSTS_VALU / SQ_WAVES / GRBM_GUI_ACTIVE child passes)")
+                if lp.get("rollout") and isinstance(out.get("rollout_roofline"), dict):
+                    rr = lp["rollout"]
+                    out["rollout_roofline"]["traffic"] = rr["hbm_bytes_per_launch"] * (E / float(rr["envs"])) * (out["rollout_roofline"].get("steps_per_launch", 80) / float(rr["steps"]))
+                    out["rollout_roofline"]["traffic_source"] = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over scripts/pmcrollout.py (KB x 1024, per launch of 80 steps)"
                 tf = lp["fp32_flop_per_launch"] / k_avg / 1e12
                 out["roofline"]["valu_fp32"] = {"bound": "valu-f32", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3, "fp32_flop_per_launch": lp["fp32_flop_per_launch"],
                                                 "active_lanes_per_valu_instruction": lp["active_lanes_per_valu_instruction"],
