@@ -34,13 +34,18 @@ def sync(env, ora):
     env.episode_length_buf = torch.from_numpy(b["ep_len"]).cuda()
 
 
-def part_a(N=512, T=150):
+def part_a(N=512, T=150, scale=1.0, settle=0, label="A"):
+    """scale / settle: the same with the robots STANDING (0.12 x the actions after `settle` oracle steps: 5.3 contacts per env, the regime of a
+    trained policy, where the floor contacts leave the collision stage through the batched pass) - part D"""
     env, ora = make_env(N, 5), orc.OracleEnv(N, seed=5, num_threads=TH)
     env.reset(); ora.reset()
     rng = np.random.default_rng(1)
+    for t in range(settle):
+        ora.step((rng.uniform(-1, 1, (N, 18)) * scale).astype(np.float32))
     errs, outl, nclose, nchecked = [], [], 0, 0
+    ncon = []
     for t in range(T):
-        a = rng.uniform(-1, 1, (N, 18)).astype(np.float32)
+        a = (rng.uniform(-1, 1, (N, 18)) * scale).astype(np.float32)
         q, v, w = ora.get_state()
         b = ora.get_buffers()
         sync(env, ora)
@@ -48,6 +53,7 @@ def part_a(N=512, T=150):
         oobs, orew, odone, _ = ora.step(a)
         e = np.maximum(np.abs(obs.cpu().numpy() - oobs).max(axis=1), np.abs(rew.cpu().numpy() - orew))
         errs.append(e)
+        if t % 10 == 0: ncon.append(np.mean([ora.data(i).ncon for i in range(0, N, 8)]))
         for i in np.nonzero(e > 1e-4)[0]:
             m, k, npair = pt.discrete_margin(orc, q[i], v[i], w[i], pt.servo_ctrl(a[i], b["dof_pos"][i]))
             outl.append((t, int(i), float(e[i]), m, k, npair))
@@ -57,8 +63,8 @@ def part_a(N=512, T=150):
                 nclose += m < 1e-6
                 nchecked += 1
     e = np.concatenate(errs)
-    print(f"A: {len(e)} env-steps: median {np.median(e):.2e} p99 {np.percentile(e, 99):.2e} p99.9 {np.percentile(e, 99.9):.2e} max {e.max():.2e}; "
-          f">1e-4: {int((e > 1e-4).sum())}; base rate of margin<1e-6: {nclose}/{nchecked}")
+    print(f"{label}: {len(e)} env-steps (action scale {scale}, {settle} settling steps, {np.mean(ncon):.2f} contacts per env): median {np.median(e):.2e} p99 {np.percentile(e, 99):.2e} "
+          f"p99.9 {np.percentile(e, 99.9):.2e} max {e.max():.2e}; >1e-4: {int((e > 1e-4).sum())}; base rate of margin<1e-6: {nclose}/{nchecked}")
     for o in outl:
         print("   outlier t=%d env=%d err=%.2e margin=%.2e kind=%s pairs=%d" % o)
 
@@ -122,7 +128,8 @@ def part_c(T=1300, K=50):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1] if len(sys.argv) > 1 else "abc"
+    which = sys.argv[1] if len(sys.argv) > 1 else "abcd"
     if "a" in which: part_a()
     if "b" in which: part_b()
     if "c" in which: part_c()
+    if "d" in which: part_a(scale=0.12, settle=600, label="D")
